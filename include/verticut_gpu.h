@@ -1,0 +1,176 @@
+/* ============================================================================
+ * verticut_gpu.h -- C ABI of the MI355X (gfx950) Hamming k-NN engine.
+ *
+ * Drop-in boundary for VertiCut's search hot path.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference tree).  Plain pointers and sizes
+ * only: no C++ types, no torch types, no exceptions, no globals; one engine handle is
+ * thread-compatible (one caller at a time, like SearchWorker, search_worker.h:35-50).
+ *
+ * Data model (reference semantics kept):
+ *   code      B/8 raw bytes, B in {64,128,256,512}  (N_BINARY_BITS image_search_constants.h:10)
+ *   id        uint32 = ordinal of the record in insertion order (+ id_base of the shard)
+ *             (build_hash_tables.cc:55,61,69; image_search.proto:4,17)
+ *   result    uint64 = id | (uint64)dist << 32      (search_worker.cc:12-13,254-256)
+ *   table t   substring t = bytes [t*B/8/m, (t+1)*B/8/m) of the code, key = little-endian
+ *             value (Pilaf/image_tools.h:12-18), one table per former MPI rank
+ *             (search_worker.cc:99-101, build_hash_tables.cc:26,36-38)
+ *
+ * All functions return VC_OK (0) or a negative VC_ERR_* code; vc_last_error() gives text.
+ * There is no CPU fallback anywhere behind this ABI: without a usable gfx950 device
+ * vc_create fails with VC_ERR_NO_DEVICE.
+ * ==========================================================================*/
+#ifndef VERTICUT_GPU_H
+#define VERTICUT_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_ABI_VERSION 1
+
+/* ---- status codes (BaseProxy uses 0 = found/done, 1 = not found/fail: base_proxy.h:10-13) */
+#define VC_OK 0
+#define VC_NOT_FOUND 1          /* == PROXY_NOT_FOUND, only from vc_get_bucket / vc_get_code */
+#define VC_ERR_INVALID (-1)     /* bad argument / configuration (reference: assert, search_worker.cc:75) */
+#define VC_ERR_NO_DEVICE (-2)   /* no gfx950 device / HIP runtime failure at create */
+#define VC_ERR_HIP (-3)         /* HIP call failed (text in vc_last_error) */
+#define VC_ERR_NOMEM (-4)       /* device allocation failed */
+#define VC_ERR_STATE (-5)       /* call order: e.g. MIH search before vc_build_index */
+#define VC_ERR_CAPACITY (-6)    /* more codes than vc_config.capacity, or output buffer too small */
+
+/* ---- search modes (which reference loop the call reproduces) */
+#define VC_MODE_LINEAR 0      /* linear_search.cc:39-64  full scan + top-k            */
+#define VC_MODE_MIH_EXACT 1   /* search_worker.cc:159-218 search_K_nearest_neighbors   */
+#define VC_MODE_MIH_APPROX 2  /* search_worker.cc:93-157  ..._approximate_... (factor 20, search_worker.h:14) */
+
+/* ---- vc_config.flags */
+#define VC_FLAG_USE_BITMAP 0x1u        /* attach the bucket-occupancy bitmap (search_worker.cc:238-243);
+                                          off = as shipped (:61-62), n_local_reads stays 0 */
+#define VC_FLAG_REF_SIGNEXT_KEYS 0x2u  /* reproduce binaryToInt's sign-extended keys for substrings < 32 bit
+                                          (Pilaf/image_tools.h:13): probes that flip the substring's top bit
+                                          can never match, exactly as in the reference.  Off = masked keys
+                                          (exact MIH for every substring width). */
+#define VC_FLAG_REF_STOP_LITERAL4 0x4u /* stop rule "kth <= 4*radius" with the literal 4 (search_worker.cc:204)
+                                          even when n_tables < 4.  Default: min(n_tables,4), identical to the
+                                          reference whenever the reference itself is exact. */
+
+/* ---- synthetic data kinds for vc_add_synthetic (the reference ships no data: .gitignore:7-8) */
+#define VC_SYNTH_UNIFORM 0
+#define VC_SYNTH_CLUSTERED 1
+
+/* ---- output order for k-NN results */
+#define VC_ORDER_ASCENDING 0       /* canonical: ascending packed (dist, id) */
+#define VC_ORDER_FARTHEST_FIRST 1  /* as SearchWorker::find / linear_search print (search_worker.cc:210-216) */
+
+typedef struct vc_engine vc_engine;
+
+typedef struct vc_config {
+  uint32_t abi_version;  /* VC_ABI_VERSION */
+  uint32_t bits;         /* code width B: 64, 128, 256 or 512            (args_config.cc binary_bits) */
+  uint32_t n_tables;     /* m, substring = B/m bits, 8..32, multiple of 8 (args_config.cc n_tables);
+                            0 = linear-only engine */
+  uint32_t flags;        /* VC_FLAG_* */
+  uint64_t capacity;     /* max number of codes this engine (shard) will hold (image_total) */
+  uint32_t id_base;      /* global id of local record 0 (shard offset; ids stay < 2^32) */
+  int32_t device;        /* HIP device ordinal, -1 = current */
+  uint32_t cand_cap;     /* per-query candidate ring entries, 0 = default (65536) */
+  uint32_t scan_blocks;  /* 0 = default grid for the verify kernel (tuning knob) */
+  uint32_t query_tile;   /* 0 = default number of queries verified per DB pass (tuning knob) */
+  uint32_t reserved[5];
+} vc_config;
+
+/* Per-query statistics == SearchWorker::get_stat (search_worker.cc:24-30, search_worker.h:42-45). */
+typedef struct vc_query_stats {
+  uint32_t radius;        /* last substring shell searched (find's return value radius-1) */
+  uint32_t n_results;     /* results written for this query (<= k) */
+  uint64_t n_main_reads;  /* always 0 (never incremented in the reference) */
+  uint64_t n_sub_reads;   /* bucket gets issued by table 0 (what rank 0's get_stat reports) */
+  uint64_t n_local_reads; /* bitmap tests by table 0 (0 unless VC_FLAG_USE_BITMAP) */
+  uint64_t n_candidates;  /* distinct DB items verified (owner-rule deduplicated) */
+} vc_query_stats;
+
+/* Timing of the most recent search call, measured with HIP events on the engine's stream. */
+typedef struct vc_timing {
+  float total_ms;       /* whole call, device side */
+  float scan_ms;        /* sum over launches of the dominant verify kernel */
+  uint32_t scan_launches;
+  uint32_t reserved;
+  uint64_t scan_bytes;  /* algorithmic bytes those launches read: passes * N * B/8 */
+} vc_timing;
+
+/* ---- lifetime ----------------------------------------------------------------------------
+ * replaces: SearchWorker ctor (search_worker.cc:50-63) + BaseProxy::init/close (base_proxy.h:24-28) */
+int vc_create(const vc_config* cfg, vc_engine** out);
+int vc_destroy(vc_engine* e);
+const char* vc_last_error(const vc_engine* e); /* never NULL; e may be NULL for create failures */
+const char* vc_strerror(int code);
+int vc_abi_version(void);
+
+/* ---- ingest ------------------------------------------------------------------------------
+ * replaces: build_hash_tables.cc:40-70 (records appended in file order, id = ordinal) and the
+ * ID -> BinaryCode put path used by linear_search.cc:45-46.  `codes` = n * bits/8 raw bytes (host). */
+int vc_add_codes(vc_engine* e, const void* codes, uint64_t n);
+/* Same, generated on the device: item with global id g gets the code of the shared definition
+ * (oracle/vc_oracle.cc gen_one) -- used by bench/tests for the BASELINE.json shapes. */
+int vc_add_synthetic(vc_engine* e, uint64_t n, uint64_t seed, uint32_t kind, uint32_t n_centres, uint32_t max_flips);
+int vc_size(const vc_engine* e, uint64_t* n);
+/* ID -> BinaryCode get (linear_search.cc:45-46; by-id query path image_search_client.h:23-25).
+ * id is a global id; out = bits/8 bytes.  VC_NOT_FOUND if id is not in this shard. */
+int vc_get_code(vc_engine* e, uint32_t id, void* out);
+
+/* ---- index -------------------------------------------------------------------------------
+ * replaces: build_hash_tables.cc (bucket contents, rule a12) + generate_bitmap.cc:105-114
+ * (bit v of table t set iff bucket (t,v) non-empty).  Must follow the last vc_add_*. */
+int vc_build_index(vc_engine* e);
+/* HashIndex{table_id,index} -> Image_List get (search_worker.cc:224-246, base_proxy.h:18).
+ * Writes up to cap (id, code) pairs in append (= id) order; *n = bucket length.
+ * Returns VC_OK (PROXY_FOUND) or VC_NOT_FOUND.  ids / codes may be NULL. */
+int vc_get_bucket(vc_engine* e, uint32_t table, uint32_t index, uint32_t* ids, void* codes, uint32_t cap, uint32_t* n);
+/* ImageBitmap::get_idx (bitmap.cc:22-26) on table t's occupancy bitmap. *bit = 0/1. */
+int vc_bitmap_test(vc_engine* e, uint32_t table, uint32_t index, int* bit);
+/* Raw bitmap words (uint32, LSB-first, 2^substr_bits bits) as generate_bitmap.cc:122-125 writes them;
+ * copies [word_off, word_off+n_words) to host memory. */
+int vc_bitmap_read(vc_engine* e, uint32_t table, uint64_t word_off, uint64_t n_words, uint32_t* out);
+
+/* ---- search ------------------------------------------------------------------------------
+ * replaces: SearchWorker::find (search_worker.cc:65-89) / linear_search.cc:39-64 for a batch of
+ * nq queries (nq * bits/8 raw bytes, host memory).
+ *   out    nq * k packed results; query i owns out[i*k .. i*k+counts[i])
+ *   counts nq entries (may be NULL): results found (< k only if the DB holds fewer items)
+ *   stats  nq entries or NULL
+ * Result set = the k smallest (dist, id) pairs among the items the mode's loop has seen
+ * (LINEAR: all items).  Ties at the k-th distance resolve to the smallest ids. */
+int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, uint32_t mode, uint32_t order,
+                  uint64_t* out, uint32_t* counts, vc_query_stats* stats);
+/* Device-pointer variant for callers that keep queries/results in HBM (torch / multi-GPU merge).
+ * d_queries: nq*bits/8 bytes; d_out: nq*k uint64, ascending, padded with UINT64_MAX; d_counts: nq uint32.
+ * Asynchronous on `stream` (a hipStream_t) when mode == VC_MODE_LINEAR; other modes synchronise. */
+int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode,
+                      uint64_t* d_out, uint32_t* d_counts, void* stream);
+/* All items within full Hamming distance <= radius of each query (BASELINE config 2; built from
+ * search_R_neighbors shells 0..radius/m, search_worker.cc:222-227).  mode LINEAR or MIH_EXACT.
+ * out_offsets: nq+1 entries; results of query i at out[out_offsets[i] .. out_offsets[i+1]),
+ * ascending packed.  VC_ERR_CAPACITY (with out_offsets filled with the needed counts) if out_cap is too small. */
+int vc_search_radius(vc_engine* e, const void* queries, uint32_t nq, uint32_t radius, uint32_t mode,
+                     uint64_t* out, uint64_t out_cap, uint64_t* out_offsets);
+
+/* ---- multi-GPU merge ---------------------------------------------------------------------
+ * replaces: mpi_coordinator::gather_vectors + master-side heap (mpi_coordinator.cc:34-69,
+ * search_worker.cc:179-199).  d_lists holds n_lists blocks of nq*k packed values (the all-gathered
+ * per-shard top-k, UINT64_MAX padded); writes the merged ascending top-k to d_out (nq*k) and the
+ * valid count per query to d_counts (may be NULL).  Asynchronous on `stream`; no engine needed. */
+int vc_merge_topk_dev(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, uint32_t k,
+                      uint64_t* d_out, uint32_t* d_counts, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+int vc_get_timing(const vc_engine* e, vc_timing* t);
+/* Bind the engine's work to a caller-owned stream (hipStream_t); NULL = engine's own stream. */
+int vc_set_stream(vc_engine* e, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VERTICUT_GPU_H */

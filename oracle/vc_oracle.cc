@@ -1,0 +1,405 @@
+// ============================================================================
+// oracle/vc_oracle.cc -- CPU restatement of VertiCut's Hamming k-NN hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+// `cpu_baseline` leg may load this library.  The product (verticut_amd/) never
+// links, imports or calls it and has no CPU fallback.
+//
+// PARITY PIN STATUS
+//   * a1 compute_hamming_dist, a2 binaryToInt, a7 ImageBitmap: PINNED -- checked
+//     bit-for-bit against the reference's own code compiled from /root/reference
+//     (oracle/ref_shim.cc -> oracle/_ref/libvcref.so) and against golden vectors
+//     generated from it (tests/golden/primitives.json, tests/golden/make_primitives.py).
+//   * a3-a6, a8, a10-a12 (SearchWorker::find loops, linear_search, builder rule):
+//     PARITY UNPINNED at loop level.  The reference holds no golden vectors for
+//     them and search_worker.cc / linear_search.cc need mpi.h and the
+//     protoc-generated image_search.pb.h, which this image lacks, so they cannot be
+//     built without stand-ins.  They are restated below line by line (citations on
+//     every function), use the same libstdc++ containers (std::priority_queue,
+//     std::map) as the reference so tie behaviour is the platform's, and are
+//     cross-validated against each other (MIH distance multiset == linear scan).
+//
+// All `file:line` citations are relative to /root/reference.
+// ============================================================================
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <map>
+#include <queue>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// a1  Pilaf/image_tools.h:21-33  compute_hamming_dist
+//     sum over len = size/4 32-bit words of popcount(p1[i]^p2[i]); bytes past the last
+//     whole 32-bit word are ignored; the length is taken from the first argument only.
+// ---------------------------------------------------------------------------
+inline int hamming32(const uint8_t* a, const uint8_t* b, size_t nbytes) {
+  const size_t nwords = nbytes / 4;
+  int dist = 0;
+  for (size_t i = 0; i < nwords; ++i) {
+    uint32_t x, y;
+    memcpy(&x, a + 4 * i, 4);
+    memcpy(&y, b + 4 * i, 4);
+    dist += __builtin_popcount(x ^ y);
+  }
+  return dist;
+}
+
+// ---------------------------------------------------------------------------
+// a2  Pilaf/image_tools.h:12-18  binaryToInt
+//     little-endian bytes -> uint32.  QUIRK kept on purpose: the top byte enters through a
+//     (signed) `char`, so for len < 4 a top byte >= 0x80 leaves 0xFF.. in the unused high
+//     bits.  For len == 4 those bits shift out.
+// ---------------------------------------------------------------------------
+inline uint32_t binary_to_int(const char* p, int len) {
+  uint32_t result = (uint32_t)(int)(signed char)p[len - 1];
+  for (int i = len - 2; i >= 0; --i) result = (result << 8) | (uint32_t)(uint8_t)p[i];
+  return result;
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic code generator shared (by definition, not by code) with the HIP generator
+// verticut_amd/csrc/vc_kernels.hip: counter-based splitmix64, so any id range can be
+// regenerated anywhere.  Not part of the reference (it ships no data: .gitignore:7-8).
+// ---------------------------------------------------------------------------
+inline uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+const uint64_t kSaltCentre = 0xC3A5C85C97CB3127ull;
+const uint64_t kSaltItem = 0xA0761D6478BD642Full;
+
+inline uint64_t uniform_word(uint64_t seed_mixed, uint64_t gid, uint32_t j) {
+  return mix64(seed_mixed ^ (gid * 16 + j));
+}
+
+void gen_one(uint64_t* w, uint32_t W, uint64_t gid, uint64_t seed, uint32_t kind,
+             uint32_t n_centres, uint32_t max_flips) {
+  if (kind == 0) {
+    const uint64_t sm = mix64(seed);
+    for (uint32_t j = 0; j < W; ++j) w[j] = uniform_word(sm, gid, j);
+    return;
+  }
+  // clustered: centre c(gid) with up to max_flips bit flips (positions may repeat).
+  const uint64_t r0 = mix64(mix64(seed ^ kSaltItem) ^ gid);
+  const uint64_t c = r0 % n_centres;
+  const uint32_t nflips = (uint32_t)((r0 >> 32) % (max_flips + 1));
+  const uint64_t cm = mix64(seed ^ kSaltCentre);
+  for (uint32_t j = 0; j < W; ++j) w[j] = uniform_word(cm, c, j);
+  for (uint32_t t = 0; t < nflips; ++t) {
+    const uint32_t pos = (uint32_t)(mix64(r0 + t + 1) % (64u * W));
+    w[pos >> 6] ^= 1ull << (pos & 63);
+  }
+}
+
+inline uint64_t pack(uint32_t dist, uint32_t id) { return ((uint64_t)dist << 32) | id; }
+
+// linear_search.cc:28-37 struct MAX + operator< (dist only)
+struct MaxItem {
+  int dist;
+  uint32_t image_id;
+};
+inline bool operator<(const MaxItem& a, const MaxItem& b) { return a.dist < b.dist; }
+
+// search_worker.h:20-23 search_result_st + search_worker.cc:15-17 operator< (dist only)
+struct ResultSt {
+  uint32_t image_id;
+  uint32_t dist;
+};
+inline bool operator<(const ResultSt& a, const ResultSt& b) { return a.dist < b.dist; }
+
+// ---------------------------------------------------------------------------
+// In-memory stand-in for the KV tier as *seen by the hot path*:
+//   HashIndex{table_id,index} -> Image_List  (search_worker.cc:224-246)
+// filled by the builder's rule a12 (build_hash_tables.cc:36-64): for every record of the
+// code file, in file order, bucket (t, binaryToInt(code + t*substr_len, substr_len)) gets
+// {id = ordinal, code} appended.
+// ---------------------------------------------------------------------------
+struct MihOracle {
+  uint32_t nbytes = 0;     // code bytes (B/8)
+  uint32_t m = 0;          // tables == MPI ranks (search_worker.cc:58,99-101)
+  uint32_t nlb = 0;        // n_local_bytes_ = nbytes / size (search_worker.cc:75-76)
+  uint32_t key_mode = 0;   // 0 = reference keys (binaryToInt incl. sign-extension quirk), 1 = masked
+  uint32_t id_base = 0;
+  uint64_t n = 0;
+  std::vector<uint8_t> codes;
+  std::vector<std::unordered_map<uint32_t, std::vector<uint32_t> > > tables;
+
+  uint32_t key_of(const uint8_t* code, uint32_t t) const {
+    uint32_t k = binary_to_int((const char*)code + t * nlb, (int)nlb);
+    if (key_mode == 1 && nlb < 4) k &= (1u << (8 * nlb)) - 1u;
+    return k;
+  }
+};
+
+struct FindCtx {
+  const MihOracle* o;
+  const uint8_t* query;
+  bool use_bitmap;
+  uint32_t table;
+  uint64_t n_sub_reads;    // search_worker.cc:245
+  uint64_t n_local_reads;  // search_worker.cc:239
+  std::vector<uint64_t>* cand;
+};
+
+// a6  search_worker.cc:230-264 enumerate_entry: all keys at Hamming distance exactly rr from
+// `curr` over bit positions len..s-1; flip-first depth-first order; leaf = bitmap test, get,
+// verify, pack.
+void enumerate_entry(FindCtx& c, uint32_t curr, int len, int rr) {
+  const int s_bits = (int)c.o->nlb * 8;
+  if (rr == 0) {
+    const auto& tab = c.o->tables[c.table];
+    auto it = tab.find(curr);
+    if (c.use_bitmap) {                      // search_worker.cc:238-243, bitmap.cc:22-26
+      c.n_local_reads++;                     // bit(v) set <=> bucket v non-empty
+      if (it == tab.end()) return;           // (generate_bitmap.cc:111-114 sets one bit per record)
+    }
+    c.n_sub_reads++;                         // search_worker.cc:245
+    if (it == tab.end()) return;             // PROXY_NOT_FOUND
+    for (uint32_t local : it->second) {      // search_worker.cc:249-257
+      const uint8_t* code = &c.o->codes[(size_t)local * c.o->nbytes];
+      uint32_t dist = (uint32_t)hamming32(code, c.query, c.o->nbytes);
+      c.cand->push_back(pack(dist, c.o->id_base + local));
+    }
+    return;
+  }
+  enumerate_entry(c, curr ^ (1u << len), len + 1, rr - 1);
+  if (s_bits - len > rr) enumerate_entry(c, curr, len + 1, rr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vco_hamming(const uint8_t* a, const uint8_t* b, size_t nbytes) { return hamming32(a, b, nbytes); }
+uint32_t vco_binary_to_int(const char* p, int len) { return binary_to_int(p, len); }
+
+// a7  bitmap.cc:22-38: bit v lives in 32-bit word v/32 under mask 1<<(v%32).
+int vco_bitmap_get(const uint32_t* data, uint64_t bit) { return (data[bit / 32] & (1u << (bit % 32))) ? 1 : 0; }
+void vco_bitmap_set(uint32_t* data, uint64_t bit) { data[bit / 32] |= (1u << (bit % 32)); }
+void vco_bitmap_reset(uint32_t* data, uint64_t bit) { data[bit / 32] &= ~(1u << (bit % 32)); }
+
+void vco_gen_codes(uint8_t* out, uint64_t first_id, uint64_t n, uint32_t bits, uint64_t seed,
+                   uint32_t kind, uint32_t n_centres, uint32_t max_flips) {
+  const uint32_t W = bits / 64;
+  uint64_t w[16];
+  for (uint64_t i = 0; i < n; ++i) {
+    gen_one(w, W, first_id + i, seed, kind, n_centres ? n_centres : 1, max_flips);
+    memcpy(out + i * (bits / 8), w, bits / 8);  // little-endian words == byte order of the code file
+  }
+}
+
+// a8  linear_search.cc:39-64: scan ids 0..n-1, max-heap of k with strict-greater replace.
+// Output in the reference's print order (farthest first), packed dist<<32|id.
+uint32_t vco_linear_knn_ref(const uint8_t* codes, uint64_t n, uint32_t nbytes, const uint8_t* query,
+                            uint32_t k, uint32_t id_base, uint64_t* out) {
+  std::priority_queue<MaxItem> qmax;
+  for (uint64_t i = 0; i < n; ++i) {
+    MaxItem item;
+    item.image_id = id_base + (uint32_t)i;
+    item.dist = hamming32(codes + i * nbytes, query, nbytes);
+    if (qmax.size() < k) {
+      qmax.push(item);
+    } else if (qmax.top().dist > item.dist) {
+      qmax.pop();
+      qmax.push(item);
+    }
+  }
+  uint32_t cnt = 0;
+  while (!qmax.empty()) {
+    MaxItem it = qmax.top();
+    qmax.pop();
+    out[cnt++] = pack((uint32_t)it.dist, it.image_id);
+  }
+  return cnt;
+}
+
+// Canonical contract: the k smallest packed (dist<<32|id) values, ascending.
+static uint32_t linear_canonical_range(const uint8_t* codes, uint64_t lo, uint64_t hi, uint32_t nbytes,
+                                       const uint8_t* query, uint32_t k, uint32_t id_base,
+                                       std::vector<uint64_t>& outv) {
+  std::priority_queue<uint64_t> h;
+  for (uint64_t i = lo; i < hi; ++i) {
+    uint64_t v = pack((uint32_t)hamming32(codes + i * nbytes, query, nbytes), id_base + (uint32_t)i);
+    if (h.size() < k) h.push(v);
+    else if (h.top() > v) { h.pop(); h.push(v); }
+  }
+  outv.resize(h.size());
+  for (size_t j = h.size(); j-- > 0;) { outv[j] = h.top(); h.pop(); }
+  return (uint32_t)outv.size();
+}
+
+uint32_t vco_linear_knn(const uint8_t* codes, uint64_t n, uint32_t nbytes, const uint8_t* query,
+                        uint32_t k, uint32_t id_base, uint64_t* out) {
+  std::vector<uint64_t> v;
+  uint32_t c = linear_canonical_range(codes, 0, n, nbytes, query, k, id_base, v);
+  if (c) memcpy(out, v.data(), c * sizeof(uint64_t));
+  return c;
+}
+
+// Same scan split over `threads` id ranges + merge (BASELINE.md row "CPU-linear-allcores").
+uint32_t vco_linear_knn_mt(const uint8_t* codes, uint64_t n, uint32_t nbytes, const uint8_t* query,
+                           uint32_t k, uint32_t id_base, uint32_t threads, uint64_t* out) {
+  if (threads < 1) threads = 1;
+  std::vector<std::vector<uint64_t> > parts(threads);
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < threads; ++t) {
+    uint64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+    th.emplace_back([=, &parts]() { linear_canonical_range(codes, lo, hi, nbytes, query, k, id_base, parts[t]); });
+  }
+  for (auto& x : th) x.join();
+  std::vector<uint64_t> all;
+  for (auto& p : parts) all.insert(all.end(), p.begin(), p.end());
+  std::sort(all.begin(), all.end());
+  uint32_t c = (uint32_t)std::min<size_t>(all.size(), k);
+  if (c) memcpy(out, all.data(), c * sizeof(uint64_t));
+  return c;
+}
+
+// ----------------------------- MIH oracle ---------------------------------
+void* vco_mih_create(const uint8_t* codes, uint64_t n, uint32_t nbytes, uint32_t m, uint32_t key_mode,
+                     uint32_t id_base) {
+  if (m == 0 || nbytes % m != 0) return nullptr;  // search_worker.cc:75 assert
+  MihOracle* o = new MihOracle();
+  o->nbytes = nbytes;
+  o->m = m;
+  o->nlb = nbytes / m;
+  if (o->nlb == 0 || o->nlb > 4) { delete o; return nullptr; }  // binaryToInt overflows past 4 bytes
+  o->key_mode = key_mode;
+  o->id_base = id_base;
+  o->n = n;
+  o->codes.assign(codes, codes + n * nbytes);
+  o->tables.resize(m);
+  for (uint64_t i = 0; i < n; ++i)                 // build_hash_tables.cc:40-70, id = ordinal
+    for (uint32_t t = 0; t < m; ++t)
+      o->tables[t][o->key_of(&o->codes[i * nbytes], t)].push_back((uint32_t)i);
+  return o;
+}
+void vco_mih_destroy(void* h) { delete static_cast<MihOracle*>(h); }
+
+// BaseProxy::get(HashIndex{table,index}, Image_List) view (base_proxy.h:18, search_worker.cc:246).
+// Returns bucket length (0 == PROXY_NOT_FOUND); ids in append (= id) order.
+uint32_t vco_mih_bucket(void* h, uint32_t table, uint32_t index, uint32_t* ids, uint32_t cap) {
+  MihOracle* o = static_cast<MihOracle*>(h);
+  auto it = o->tables[table].find(index);
+  if (it == o->tables[table].end()) return 0;
+  uint32_t nb = (uint32_t)it->second.size();
+  for (uint32_t i = 0; i < nb && i < cap; ++i) ids[i] = o->id_base + it->second[i];
+  return nb;
+}
+uint32_t vco_mih_key(void* h, const uint8_t* code, uint32_t table) {
+  return static_cast<MihOracle*>(h)->key_of(code, table);
+}
+
+struct vco_find_stats {
+  uint32_t radius;          // search_worker.cc:84-86: value returned by the search loop (radius-1)
+  uint32_t n_results;
+  uint64_t n_main_reads;    // never incremented in the reference (search_worker.cc:24-30)
+  uint64_t n_sub_reads;     // rank 0's counter, as get_stat on the master reports
+  uint64_t n_local_reads;   // rank 0's counter
+  uint64_t n_sub_reads_all;    // summed over all ranks (not observable in the reference; for GPU stats)
+  uint64_t n_local_reads_all;
+  uint64_t n_candidates;    // total gathered values over all iterations (before dedup)
+  uint64_t n_distinct;      // knn_found_.size() at exit
+};
+
+// a3-a5  SearchWorker::find (search_worker.cc:65-89) with the m MPI ranks simulated in rank
+// order inside one thread: per radius iteration every rank runs search_R_neighbors
+// (:222-227) for its table, mpi_coordinator::gather_vectors concatenates in rank order
+// (mpi_coordinator.cc:34-69), rank 0 dedups (std::map<int,bool>, search_worker.h:40) and
+// feeds a std::priority_queue, then the stop flag is broadcast.
+//   exact  (:159-218): heap cap k, stop iff size==k && top.dist <= radius*stop_mult after radius+=1
+//                      (stop_mult: the reference's literal is 4, :204)
+//   approx (:93-157):  heap cap k*20 (search_worker.h:14), stop iff heap full; emit only the last
+//                      k pops (:142-155)
+// Output: reference order = farthest first, packed dist<<32|id.
+uint32_t vco_mih_find(void* h, const uint8_t* query, uint32_t k, int approximate, int use_bitmap,
+                      uint32_t stop_mult, uint64_t* out, vco_find_stats* st) {
+  MihOracle* o = static_cast<MihOracle*>(h);
+  const uint32_t s_bits = o->nlb * 8;
+  std::priority_queue<ResultSt> qmax;
+  std::map<int, bool> knn_found;
+  size_t radius = 0;
+  int is_stop = 0;
+  const size_t heap_cap = approximate ? (size_t)k * 20 : (size_t)k;
+  std::vector<uint32_t> search_index(o->m);
+  for (uint32_t t = 0; t < o->m; ++t)
+    search_index[t] = binary_to_int((const char*)query + t * o->nlb, (int)o->nlb);  // :165-167 (unmasked, as in the reference)
+  std::vector<uint64_t> sub(o->m, 0), loc(o->m, 0);
+  uint64_t n_cand = 0;
+
+  while (!is_stop && radius <= s_bits) {            // :170 / :104
+    std::vector<uint64_t> gathered;
+    for (uint32_t t = 0; t < o->m; ++t) {           // ranks in gather order
+      FindCtx c{o, query, use_bitmap != 0, t, 0, 0, &gathered};
+      uint32_t start = search_index[t];
+      if (o->key_mode == 1 && o->nlb < 4) start &= (1u << s_bits) - 1u;
+      enumerate_entry(c, start, 0, (int)radius);
+      sub[t] += c.n_sub_reads;
+      loc[t] += c.n_local_reads;
+    }
+    n_cand += gathered.size();
+    for (size_t i = 0; i < gathered.size(); ++i) {  // :179-199 / :113-132
+      uint32_t id = (uint32_t)(gathered[i] & 0xffffffffu);
+      if (knn_found.find((int)id) != knn_found.end()) continue;
+      ResultSt item;
+      item.image_id = id;
+      item.dist = (uint32_t)(gathered[i] >> 32);
+      knn_found[(int)id] = 1;
+      if (qmax.size() < heap_cap) {
+        qmax.push(item);
+      } else if (qmax.top().dist > item.dist) {
+        qmax.pop();
+        qmax.push(item);
+      }
+    }
+    radius += 1;
+    if (approximate) {
+      if (qmax.size() == heap_cap) is_stop = 1;                                   // :136-137
+    } else {
+      if (qmax.size() == k && qmax.top().dist <= radius * stop_mult) is_stop = 1;  // :204-205
+    }
+  }
+
+  uint32_t cnt = 0;
+  if (approximate) {                                // :142-155
+    int i = 0;
+    int beg = (int)(qmax.size() - (size_t)k);
+    while (!qmax.empty()) {
+      ResultSt it = qmax.top();
+      if (i >= beg) out[cnt++] = pack(it.dist, it.image_id);
+      qmax.pop();
+      i++;
+    }
+  } else {                                          // :210-216
+    while (!qmax.empty()) {
+      ResultSt it = qmax.top();
+      out[cnt++] = pack(it.dist, it.image_id);
+      qmax.pop();
+    }
+  }
+  if (st) {
+    st->radius = (uint32_t)(radius - 1);
+    st->n_results = cnt;
+    st->n_main_reads = 0;
+    st->n_sub_reads = sub[0];
+    st->n_local_reads = loc[0];
+    st->n_sub_reads_all = 0;
+    st->n_local_reads_all = 0;
+    for (uint32_t t = 0; t < o->m; ++t) { st->n_sub_reads_all += sub[t]; st->n_local_reads_all += loc[t]; }
+    st->n_candidates = n_cand;
+    st->n_distinct = knn_found.size();
+  }
+  return cnt;
+}
+
+}  // extern "C"

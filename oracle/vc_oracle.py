@@ -1,0 +1,204 @@
+"""ctypes loader for the CPU oracle (oracle/vc_oracle.cc) and, when built, the reference
+veneer (oracle/_ref/libvcref.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (verticut_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libvcoracle.so")
+_REF = os.path.join(_HERE, "_ref", "libvcref.so")
+
+
+def build(ref=True):
+    """Compile the oracle (always) and the reference veneer (only where /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if ref and os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+class FindStats(C.Structure):
+    _fields_ = [
+        ("radius", C.c_uint32),
+        ("n_results", C.c_uint32),
+        ("n_main_reads", C.c_uint64),
+        ("n_sub_reads", C.c_uint64),
+        ("n_local_reads", C.c_uint64),
+        ("n_sub_reads_all", C.c_uint64),
+        ("n_local_reads_all", C.c_uint64),
+        ("n_candidates", C.c_uint64),
+        ("n_distinct", C.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build(ref=False)
+        L = C.CDLL(_LIB)
+        u8p = C.c_void_p
+        L.vco_hamming.restype = C.c_int
+        L.vco_hamming.argtypes = [u8p, u8p, C.c_size_t]
+        L.vco_binary_to_int.restype = C.c_uint32
+        L.vco_binary_to_int.argtypes = [C.c_char_p, C.c_int]
+        L.vco_bitmap_get.restype = C.c_int
+        L.vco_bitmap_get.argtypes = [u8p, C.c_uint64]
+        L.vco_bitmap_set.argtypes = [u8p, C.c_uint64]
+        L.vco_bitmap_reset.argtypes = [u8p, C.c_uint64]
+        L.vco_gen_codes.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
+                                    C.c_uint32, C.c_uint32]
+        for f in (L.vco_linear_knn_ref, L.vco_linear_knn):
+            f.restype = C.c_uint32
+            f.argtypes = [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint32, C.c_uint32, u8p]
+        L.vco_linear_knn_mt.restype = C.c_uint32
+        L.vco_linear_knn_mt.argtypes = [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
+        L.vco_mih_create.restype = C.c_void_p
+        L.vco_mih_create.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.vco_mih_destroy.argtypes = [C.c_void_p]
+        L.vco_mih_bucket.restype = C.c_uint32
+        L.vco_mih_bucket.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u8p, C.c_uint32]
+        L.vco_mih_key.restype = C.c_uint32
+        L.vco_mih_key.argtypes = [C.c_void_p, u8p, C.c_uint32]
+        L.vco_mih_find.restype = C.c_uint32
+        L.vco_mih_find.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_int, C.c_int, C.c_uint32, u8p,
+                                   C.POINTER(FindStats)]
+        _lib = L
+    return _lib
+
+
+_ref = None
+
+
+def ref():
+    """The reference's own compute_hamming_dist / binaryToInt / ImageBitmap, or None if not built."""
+    global _ref
+    if _ref is None and os.path.exists(_REF):
+        R = C.CDLL(_REF)
+        R.vcref_hamming.restype = C.c_int
+        R.vcref_hamming.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        R.vcref_binary_to_int.restype = C.c_uint32
+        R.vcref_binary_to_int.argtypes = [C.c_char_p, C.c_int]
+        R.vcref_bitmap_new.restype = C.c_void_p
+        R.vcref_bitmap_new.argtypes = [C.c_ulong]
+        R.vcref_bitmap_free.argtypes = [C.c_void_p]
+        R.vcref_bitmap_set.argtypes = [C.c_void_p, C.c_ulong]
+        R.vcref_bitmap_reset.argtypes = [C.c_void_p, C.c_ulong]
+        R.vcref_bitmap_get.restype = C.c_int
+        R.vcref_bitmap_get.argtypes = [C.c_void_p, C.c_ulong]
+        R.vcref_bitmap_data.restype = C.c_void_p
+        R.vcref_bitmap_data.argtypes = [C.c_void_p]
+        _ref = R
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _bytes(a):
+    a = np.ascontiguousarray(a)
+    assert a.dtype == np.uint8
+    return a
+
+
+# ------------------------------------------------------------------ primitives
+def hamming(a, b):
+    a, b = _bytes(a), _bytes(b)
+    return lib().vco_hamming(_p(a), _p(b), a.size)
+
+
+def binary_to_int(raw: bytes, length=None):
+    return lib().vco_binary_to_int(raw, len(raw) if length is None else length)
+
+
+def gen_codes(n, bits, seed, kind=0, n_centres=0, max_flips=0, first_id=0):
+    """Synthetic DB (row-major uint8 [n, bits/8]); same definition as the HIP generator."""
+    out = np.empty((n, bits // 8), dtype=np.uint8)
+    lib().vco_gen_codes(_p(out), first_id, n, bits, seed, kind, n_centres, max_flips)
+    return out
+
+
+# ------------------------------------------------------------------ linear scan
+def linear_knn_ref(codes, query, k, id_base=0):
+    """linear_search.cc:39-64 order (farthest first); returns packed uint64 array."""
+    codes, query = _bytes(codes), _bytes(query)
+    out = np.empty(max(k, 1), dtype=np.uint64)
+    c = lib().vco_linear_knn_ref(_p(codes), codes.shape[0], codes.shape[1], _p(query), k, id_base, _p(out))
+    return out[:c].copy()
+
+
+def linear_knn(codes, query, k, id_base=0, threads=1):
+    """Canonical contract: the k smallest packed dist<<32|id, ascending."""
+    codes, query = _bytes(codes), _bytes(query)
+    out = np.empty(max(k, 1), dtype=np.uint64)
+    if threads > 1:
+        c = lib().vco_linear_knn_mt(_p(codes), codes.shape[0], codes.shape[1], _p(query), k, id_base, threads, _p(out))
+    else:
+        c = lib().vco_linear_knn(_p(codes), codes.shape[0], codes.shape[1], _p(query), k, id_base, _p(out))
+    return out[:c].copy()
+
+
+# ------------------------------------------------------------------ MIH
+class MihOracle:
+    """SearchWorker (search_worker.cc) over in-memory buckets built by rule a12."""
+
+    def __init__(self, codes, m, key_mode=0, id_base=0):
+        codes = _bytes(codes)
+        self.codes = codes
+        self.m = m
+        self.h = lib().vco_mih_create(_p(codes), codes.shape[0], codes.shape[1], m, key_mode, id_base)
+        if not self.h:
+            raise ValueError("bad (nbytes, m)")
+
+    def close(self):
+        if self.h:
+            lib().vco_mih_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def key(self, code, table):
+        code = _bytes(code)
+        return lib().vco_mih_key(self.h, _p(code), table)
+
+    def bucket(self, table, index, cap=1 << 20):
+        ids = np.empty(cap, dtype=np.uint32)
+        n = lib().vco_mih_bucket(self.h, table, index, _p(ids), cap)
+        return ids[: min(n, cap)].copy()
+
+    def find(self, query, k, approximate=False, use_bitmap=False, stop_mult=4):
+        """Returns (packed farthest-first, FindStats)."""
+        query = _bytes(query)
+        out = np.empty(max(k, 1) * (1 if not approximate else 1) + 8, dtype=np.uint64)
+        st = FindStats()
+        c = lib().vco_mih_find(self.h, _p(query), k, int(approximate), int(use_bitmap), stop_mult, _p(out), C.byref(st))
+        return out[:c].copy(), st
+
+
+# ------------------------------------------------------------------ numpy helpers (contract checks)
+def np_distances(codes, query):
+    """Full Hamming distances of every row to query (numpy; independent of the C code)."""
+    x = np.bitwise_xor(_bytes(codes), _bytes(query)[None, :])
+    return np.unpackbits(x, axis=1).sum(axis=1).astype(np.uint32)
+
+
+def np_sub_distances(codes, query, m):
+    """[n, m] per-substring distances (substring t = bytes [t*nlb, (t+1)*nlb))."""
+    codes = _bytes(codes)
+    n, nb = codes.shape
+    x = np.bitwise_xor(codes, _bytes(query)[None, :])
+    bits = np.unpackbits(x, axis=1).reshape(n, m, -1)
+    return bits.sum(axis=2).astype(np.uint32)
+
+
+def pack(dist, ids):
+    return (dist.astype(np.uint64) << np.uint64(32)) | ids.astype(np.uint64)

@@ -1,0 +1,106 @@
+"""GPU parity of the linear verify path (linear_search.cc:39-64) against the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _queries(vo, codes, nq, rng, flips=6):
+    """half near-duplicates of DB items (query-by-image use, image_search_client.h:23-25), half uniform."""
+    nb = codes.shape[1]
+    q = rng.integers(0, 256, size=(nq, nb), dtype=np.uint8)
+    for i in range(0, nq, 2):
+        q[i] = codes[rng.integers(0, codes.shape[0])]
+        for _ in range(rng.integers(0, flips + 1)):
+            b = rng.integers(0, nb * 8)
+            q[i, b // 8] ^= np.uint8(1 << (b % 8))
+    return q
+
+
+def _expect(vo, codes, q, k, id_base=0):
+    out = np.full((q.shape[0], k), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    cnt = np.zeros(q.shape[0], dtype=np.uint32)
+    for i in range(q.shape[0]):
+        r = vo.linear_knn(codes, q[i], k, id_base=id_base)
+        out[i, : len(r)] = r
+        cnt[i] = len(r)
+    return out, cnt
+
+
+def test_synthetic_generator_matches_oracle(vc, oracle):
+    for bits, kind in ((64, 0), (128, 0), (128, 1), (256, 1), (512, 0)):
+        n = 5000
+        with vc.Engine(bits, capacity=n, id_base=1000) as e:
+            e.add_synthetic(n, seed=34, kind=kind, n_centres=50, max_flips=9)
+            ref = oracle.gen_codes(n, bits, 34, kind=kind, n_centres=50, max_flips=9, first_id=1000)
+            for gid in (1000, 1001, 1063, 1064, 3333, 5999):
+                assert np.array_equal(e.get_code(gid), ref[gid - 1000]), (bits, kind, gid)
+            assert e.get_code(999) is None and e.get_code(6000) is None
+
+
+@pytest.mark.parametrize("bits", [64, 128, 256, 512])
+@pytest.mark.parametrize("n,k,kind", [(4096, 1, 0), (4097, 10, 0), (70001, 100, 0), (70001, 100, 1), (300000, 1000, 1)])
+def test_linear_knn_bit_exact(vc, oracle, bits, n, k, kind):
+    rng = np.random.default_rng(bits * 7 + n + k)
+    codes = oracle.gen_codes(n, bits, 34, kind=kind, n_centres=200, max_flips=11)
+    with vc.Engine(bits, capacity=n) as e:
+        e.add_synthetic(n, seed=34, kind=kind, n_centres=200, max_flips=11)
+        q = _queries(oracle, codes, 21, rng)   # 21: not a multiple of the query tile
+        got, cnt = e.search_knn(q, k)
+        exp, ecnt = _expect(oracle, codes, q, k)
+        assert np.array_equal(cnt, ecnt)
+        assert np.array_equal(got, exp)
+
+
+def test_add_codes_rows_idbase_and_order(vc, oracle):
+    rng = np.random.default_rng(5)
+    n, bits, k = 33333, 128, 50
+    codes = rng.integers(0, 256, size=(n, bits // 8), dtype=np.uint8)
+    with vc.Engine(bits, capacity=n + 10, id_base=4_000_000_000) as e:
+        e.add_codes(codes[:10000])
+        e.add_codes(codes[10000:])
+        assert len(e) == n
+        q = _queries(oracle, codes, 5, rng)
+        got, cnt = e.search_knn(q, k)
+        exp, _ = _expect(oracle, codes, q, k, id_base=4_000_000_000)
+        assert np.array_equal(got, exp)
+        far, _ = e.search_knn(q, k, order=vc.ORDER_FARTHEST_FIRST)
+        assert np.array_equal(far, exp[:, ::-1])
+        # reference order (linear_search.cc:59-63) has the same distance sequence
+        ref = oracle.linear_knn_ref(codes, q[0], k, id_base=4_000_000_000)
+        assert np.array_equal(ref >> np.uint64(32), far[0] >> np.uint64(32))
+
+
+def test_fewer_items_than_k(vc, oracle):
+    rng = np.random.default_rng(9)
+    codes = rng.integers(0, 256, size=(37, 16), dtype=np.uint8)
+    with vc.Engine(128, capacity=64) as e:
+        e.add_codes(codes)
+        q = codes[:3].copy()
+        got, cnt = e.search_knn(q, 100)
+        exp, ecnt = _expect(oracle, codes, q, 100)
+        assert list(cnt) == [37, 37, 37]
+        assert np.array_equal(got, exp)
+
+
+def test_many_exact_duplicates(vc, oracle):
+    """ties at the k-th distance resolve to the smallest ids (canonical contract)."""
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 256, size=(50, 16), dtype=np.uint8)
+    codes = np.repeat(base, 400, axis=0)           # 20000 items, 400 copies of each
+    codes = codes[rng.permutation(codes.shape[0])]
+    with vc.Engine(128, capacity=codes.shape[0]) as e:
+        e.add_codes(codes)
+        q = base[:4].copy()
+        got, _ = e.search_knn(q, 100)
+        exp, _ = _expect(oracle, codes, q, 100)
+        assert np.array_equal(got, exp)
+
+
+def test_timing_reports_scan(vc):
+    with vc.Engine(128, capacity=1 << 20) as e:
+        e.add_synthetic(1 << 20, seed=1)
+        q = np.zeros((4, 16), dtype=np.uint8)
+        e.search_knn(q, 10)
+        t = e.timing()
+        assert t.scan_launches == 1 and t.scan_bytes == (1 << 20) * 16 and t.scan_ms > 0

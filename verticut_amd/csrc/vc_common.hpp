@@ -1,0 +1,81 @@
+// Shared host/device definitions for the gfx950 Hamming k-NN engine.
+// Wave width is 64 everywhere (CDNA4); nothing here is written for 32-wide warps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/verticut_gpu.h"
+
+#define VC_WAVE 64
+#define VC_MAX_K 8192u           // LDS bitonic capacity of the select kernel (64 KiB of uint64)
+#define VC_SORT_CAP 8192u
+#define VC_PAD_ITEMS 8192ull     // column stride granularity: every scan chunk shape divides this
+#define VC_MAX_W 8               // 512-bit codes
+#define VC_PACK_INF 0xFFFFFFFFFFFFFFFFull
+
+// native 16-byte vector (two uint64): one global_load_dwordx4 per lane
+typedef unsigned long long vc_u64x2 __attribute__((ext_vector_type(2)));
+
+// ---- synthetic generator (definition shared with oracle/vc_oracle.cc gen_one) ----------------
+__host__ __device__ inline uint64_t vc_mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+#define VC_SALT_CENTRE 0xC3A5C85C97CB3127ull
+#define VC_SALT_ITEM 0xA0761D6478BD642Full
+
+// result packing: search_worker.cc:254-256 (id | dist << 32)
+__host__ __device__ inline uint64_t vc_pack(uint32_t dist, uint32_t id) { return ((uint64_t)dist << 32) | id; }
+
+// ---- wave64 helpers --------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t vc_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// exclusive prefix sum over the 64 lanes of a wave (cold paths only: shuffle ladder)
+__device__ __forceinline__ uint32_t vc_wave_excl_scan(uint32_t v, uint32_t& total) {
+  const uint32_t lane = vc_lane();
+  uint32_t x = v;
+#pragma unroll
+  for (int off = 1; off < VC_WAVE; off <<= 1) {
+    uint32_t y = __shfl_up(x, off, VC_WAVE);
+    if (lane >= (uint32_t)off) x += y;
+  }
+  total = __shfl(x, VC_WAVE - 1, VC_WAVE);
+  return x - v;
+}
+
+__device__ __forceinline__ uint32_t vc_wave_min(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t y = __shfl_xor(v, off, VC_WAVE);
+    v = y < v ? y : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t vc_ld_relaxed(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- engine-internal structures ----------------------------------------------------------------
+struct VcScanParams {
+  const uint64_t* cols;   // W columns of `stride` uint64 each: word j of item i at cols[j*stride + i]
+  uint64_t stride;
+  uint64_t n;             // valid items
+  uint64_t nchunks;       // ceil(n / chunk_items)
+  uint32_t id_base;
+  uint32_t qt;            // queries in this tile
+  uint32_t k;
+  uint32_t cap;           // candidate ring entries per query
+  uint32_t hist_stride;   // uint32 per query in hist
+  uint32_t pad;
+  const uint64_t* queries;  // [qt][W]
+  uint32_t* tau;            // [qt] distance threshold, shared by every wave of the grid
+  uint32_t* count;          // [qt] append cursor
+  uint32_t* hist;           // [qt][hist_stride] histogram of appended distances
+  uint64_t* buf;            // [qt][cap] appended packed candidates
+};

@@ -1,0 +1,497 @@
+// ============================================================================
+// vc_engine.hip -- host side of the C ABI declared in include/verticut_gpu.h.
+// Owns the HBM-resident code columns, the per-call work buffers and the launch sequence.
+// No CPU compute path exists here: every search runs on the device or fails.
+// ============================================================================
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "vc_internal.hpp"
+#include "vc_mih.hpp"
+
+struct vc_engine {
+  vc_config cfg;
+  int device = 0;
+  uint32_t bits = 0, W = 0, m = 0, sbits = 0, n_cu = 0;
+  uint32_t cap = 65536, qtile = 16, scan_blocks = 0;
+  uint64_t n = 0, stride = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  uint64_t* d_cols = nullptr;
+
+  // grow-only work buffers
+  void* d_stage = nullptr;      size_t stage_bytes = 0;   // ingest staging / query upload
+  uint64_t* d_q = nullptr;      size_t q_bytes = 0;       // queries [nq][W]
+  uint32_t* d_state = nullptr;  size_t state_bytes = 0;   // per tile: count | hist | shist | tau
+  uint64_t* d_ring = nullptr;   size_t ring_bytes = 0;    // per tile: [qt][cap]
+  uint64_t* d_out = nullptr;    size_t out_bytes = 0;     // [nq][k]
+  uint32_t* d_cnt = nullptr;    size_t cnt_bytes = 0;     // [nq] result counts | [nq] raw ring counts
+
+  // timing
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  bool timing_pending = false;
+  uint64_t scan_bytes = 0;
+  vc_timing last{};
+
+  VcMihIndex* mih = nullptr;
+  std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(vc_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf; else g_create_err = buf;
+  return code;
+}
+
+#define VC_HIP(e, call)                                                                         \
+  do {                                                                                          \
+    hipError_t _r = (call);                                                                     \
+    if (_r != hipSuccess)                                                                       \
+      return fail(e, _r == hipErrorOutOfMemory ? VC_ERR_NOMEM : VC_ERR_HIP, "%s: %s (%s:%d)", #call, \
+                  hipGetErrorString(_r), __FILE__, __LINE__);                                   \
+  } while (0)
+
+template <class T>
+static int grow(vc_engine* e, T** p, size_t* have, size_t need) {
+  if (need <= *have) return VC_OK;
+  if (*p) VC_HIP(e, hipFree(*p));
+  *p = nullptr;
+  *have = 0;
+  need = (need + 255) & ~(size_t)255;
+  VC_HIP(e, hipMalloc((void**)p, need));
+  *have = need;
+  return VC_OK;
+}
+
+static int bind_device(vc_engine* e) {
+  VC_HIP(e, hipSetDevice(e->device));
+  return VC_OK;
+}
+
+extern "C" {
+
+int vc_abi_version(void) { return VC_ABI_VERSION; }
+
+const char* vc_strerror(int code) {
+  switch (code) {
+    case VC_OK: return "ok";
+    case VC_NOT_FOUND: return "not found";
+    case VC_ERR_INVALID: return "invalid argument";
+    case VC_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case VC_ERR_HIP: return "HIP runtime error";
+    case VC_ERR_NOMEM: return "out of device memory";
+    case VC_ERR_STATE: return "call made in the wrong state";
+    case VC_ERR_CAPACITY: return "capacity exceeded";
+  }
+  return "unknown error";
+}
+
+const char* vc_last_error(const vc_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int vc_create(const vc_config* cfg, vc_engine** out) {
+  if (!cfg || !out) return fail(nullptr, VC_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != VC_ABI_VERSION) return fail(nullptr, VC_ERR_INVALID, "abi_version %u != %u", cfg->abi_version, VC_ABI_VERSION);
+  const uint32_t B = cfg->bits;
+  if (!(B == 64 || B == 128 || B == 256 || B == 512)) return fail(nullptr, VC_ERR_INVALID, "bits must be 64/128/256/512");
+  uint32_t sbits = 0;
+  if (cfg->n_tables) {  // search_worker.cc:75 assert(nbytes % size == 0); binaryToInt handles <= 4 bytes
+    if ((B / 8) % cfg->n_tables) return fail(nullptr, VC_ERR_INVALID, "code bytes not divisible by n_tables");
+    sbits = B / cfg->n_tables;
+    if (sbits < 8 || sbits > 32 || sbits % 8) return fail(nullptr, VC_ERR_INVALID, "substring must be 8..32 bits, multiple of 8");
+  }
+  if (cfg->capacity == 0 || cfg->capacity + (uint64_t)cfg->id_base > 0x100000000ull)
+    return fail(nullptr, VC_ERR_INVALID, "capacity must be >0 and id_base+capacity <= 2^32 (ids are uint32)");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, VC_ERR_NO_DEVICE, "no HIP device visible");
+  int dev = cfg->device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(nullptr, VC_ERR_NO_DEVICE, "hipGetDevice failed");
+  if (dev >= ndev) return fail(nullptr, VC_ERR_NO_DEVICE, "device %d out of range", dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(nullptr, VC_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, VC_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", dev, prop.gcnArchName);
+
+  vc_engine* e = new vc_engine();
+  e->cfg = *cfg;
+  e->device = dev;
+  e->bits = B;
+  e->W = B / 64;
+  e->m = cfg->n_tables;
+  e->sbits = sbits;
+  e->n_cu = (uint32_t)prop.multiProcessorCount;
+  e->cap = cfg->cand_cap ? cfg->cand_cap : 65536u;
+  e->qtile = cfg->query_tile ? cfg->query_tile : 16u;
+  if (const char* s = getenv("VC_QUERY_TILE")) e->qtile = (uint32_t)std::max(1, atoi(s));
+  e->scan_blocks = cfg->scan_blocks;
+  if (const char* s = getenv("VC_SCAN_BLOCKS")) e->scan_blocks = (uint32_t)std::max(1, atoi(s));
+  e->stride = (cfg->capacity + VC_PAD_ITEMS - 1) / VC_PAD_ITEMS * VC_PAD_ITEMS;
+
+  int rc = bind_device(e);
+  if (rc == VC_OK) {
+    hipError_t r = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (r == hipSuccess) r = hipEventCreate(&e->ev_t0);
+    if (r == hipSuccess) r = hipEventCreate(&e->ev_t1);
+    if (r == hipSuccess) r = hipMalloc((void**)&e->d_cols, e->stride * e->W * sizeof(uint64_t));
+    if (r == hipSuccess) r = hipMemsetAsync(e->d_cols, 0, e->stride * e->W * sizeof(uint64_t), e->own_stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->own_stream);
+    if (r != hipSuccess) rc = fail(nullptr, r == hipErrorOutOfMemory ? VC_ERR_NOMEM : VC_ERR_HIP, "engine setup: %s", hipGetErrorString(r));
+  } else {
+    g_create_err = e->err;
+  }
+  if (rc != VC_OK) {
+    vc_destroy(e);
+    return rc;
+  }
+  e->stream = e->own_stream;
+  *out = e;
+  return VC_OK;
+}
+
+int vc_destroy(vc_engine* e) {
+  if (!e) return VC_OK;
+  (void)hipSetDevice(e->device);
+  if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+  if (e->mih) vc_mih_free(e->mih);
+  (void)hipFree(e->d_cols);
+  (void)hipFree(e->d_stage);
+  (void)hipFree(e->d_q);
+  (void)hipFree(e->d_state);
+  (void)hipFree(e->d_ring);
+  (void)hipFree(e->d_out);
+  (void)hipFree(e->d_cnt);
+  for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+  if (e->ev_t0) (void)hipEventDestroy(e->ev_t0);
+  if (e->ev_t1) (void)hipEventDestroy(e->ev_t1);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+  return VC_OK;
+}
+
+int vc_set_stream(vc_engine* e, void* stream) {
+  if (!e) return VC_ERR_INVALID;
+  e->stream = stream ? (hipStream_t)stream : e->own_stream;
+  return VC_OK;
+}
+
+int vc_size(const vc_engine* e, uint64_t* n) {
+  if (!e || !n) return VC_ERR_INVALID;
+  *n = e->n;
+  return VC_OK;
+}
+
+// ---- ingest (build_hash_tables.cc:40-70: append in file order, id = ordinal) ---------------------
+int vc_add_codes(vc_engine* e, const void* codes, uint64_t n) {
+  if (!e || (!codes && n)) return VC_ERR_INVALID;
+  if (e->n + n > e->cfg.capacity) return fail(e, VC_ERR_CAPACITY, "add %llu codes: %llu + n > capacity %llu", (unsigned long long)n, (unsigned long long)e->n, (unsigned long long)e->cfg.capacity);
+  int rc = bind_device(e);
+  if (rc) return rc;
+  const size_t rec = e->bits / 8;
+  const uint64_t batch = std::max<uint64_t>(1, (64ull << 20) / rec);
+  const uint8_t* src = (const uint8_t*)codes;
+  for (uint64_t off = 0; off < n; off += batch) {
+    const uint64_t cnt = std::min(batch, n - off);
+    if ((rc = grow(e, (uint8_t**)&e->d_stage, &e->stage_bytes, cnt * rec))) return rc;
+    VC_HIP(e, hipMemcpyAsync(e->d_stage, src + off * rec, cnt * rec, hipMemcpyHostToDevice, e->stream));
+    VC_HIP(e, vc_launch_rows_to_cols((const uint64_t*)e->d_stage, e->d_cols, e->stride, e->W, e->n + off, cnt, e->stream));
+    VC_HIP(e, hipStreamSynchronize(e->stream));
+  }
+  e->n += n;
+  if (e->mih) { vc_mih_free(e->mih); e->mih = nullptr; }
+  return VC_OK;
+}
+
+int vc_add_synthetic(vc_engine* e, uint64_t n, uint64_t seed, uint32_t kind, uint32_t n_centres, uint32_t max_flips) {
+  if (!e || kind > VC_SYNTH_CLUSTERED) return VC_ERR_INVALID;
+  if (e->n + n > e->cfg.capacity) return fail(e, VC_ERR_CAPACITY, "add_synthetic beyond capacity");
+  int rc = bind_device(e);
+  if (rc) return rc;
+  VC_HIP(e, vc_launch_fill_synth(e->d_cols, e->stride, e->W, e->n, n, (uint64_t)e->cfg.id_base + e->n, seed, kind, n_centres, max_flips, e->stream));
+  VC_HIP(e, hipStreamSynchronize(e->stream));
+  e->n += n;
+  if (e->mih) { vc_mih_free(e->mih); e->mih = nullptr; }
+  return VC_OK;
+}
+
+int vc_get_code(vc_engine* e, uint32_t id, void* out) {
+  if (!e || !out) return VC_ERR_INVALID;
+  if (id < e->cfg.id_base || (uint64_t)id - e->cfg.id_base >= e->n) return VC_NOT_FOUND;
+  int rc = bind_device(e);
+  if (rc) return rc;
+  const uint64_t local = id - e->cfg.id_base;
+  uint64_t w[VC_MAX_W];
+  for (uint32_t j = 0; j < e->W; ++j)
+    VC_HIP(e, hipMemcpyAsync(&w[j], e->d_cols + j * e->stride + local, 8, hipMemcpyDeviceToHost, e->stream));
+  VC_HIP(e, hipStreamSynchronize(e->stream));
+  memcpy(out, w, e->bits / 8);
+  return VC_OK;
+}
+
+// ---- timing helpers -----------------------------------------------------------------------------
+static int ev_pair(vc_engine* e, hipEvent_t* a, hipEvent_t* b) {
+  while (e->ev.size() < e->ev_used + 2) {
+    hipEvent_t ev;
+    VC_HIP(e, hipEventCreate(&ev));
+    e->ev.push_back(ev);
+  }
+  *a = e->ev[e->ev_used++];
+  *b = e->ev[e->ev_used++];
+  return VC_OK;
+}
+
+static void timing_begin(vc_engine* e) {
+  e->ev_used = 0;
+  e->scan_bytes = 0;
+  e->timing_pending = true;
+  (void)hipEventRecord(e->ev_t0, e->stream);
+}
+static void timing_end(vc_engine* e) { (void)hipEventRecord(e->ev_t1, e->stream); }
+
+int vc_get_timing(const vc_engine* ce, vc_timing* t) {
+  vc_engine* e = const_cast<vc_engine*>(ce);
+  if (!e || !t) return VC_ERR_INVALID;
+  if (e->timing_pending) {
+    int rc = bind_device(e);
+    if (rc) return rc;
+    VC_HIP(e, hipEventSynchronize(e->ev_t1));
+    vc_timing lt{};
+    (void)hipEventElapsedTime(&lt.total_ms, e->ev_t0, e->ev_t1);
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]);
+      lt.scan_ms += ms;
+      lt.scan_launches++;
+    }
+    lt.scan_bytes = e->scan_bytes;
+    e->last = lt;
+    e->timing_pending = false;
+  }
+  *t = e->last;
+  return VC_OK;
+}
+
+// ---- LINEAR: linear_search.cc:39-64 for a batch of queries ------------------------------------------
+// d_q: [nq][W] words on the device.  Results: d_out [nq][k] ascending (INF padded), d_cnt[0..nq) counts,
+// d_cnt[nq..2nq) raw ring counts (overflow detection).
+static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_cnt,
+                        uint32_t* d_raw) {
+  const uint32_t hs = (e->bits + 1 + 7) & ~7u;
+  const uint32_t QT = std::min(e->qtile, nq);
+  const uint32_t cap = std::max(e->cap, 4 * k);
+  int rc;
+  const size_t state_words = (size_t)QT * (1 + 2 * (size_t)hs + 1);
+  if ((rc = grow(e, &e->d_state, &e->state_bytes, state_words * 4))) return rc;
+  if ((rc = grow(e, &e->d_ring, &e->ring_bytes, (size_t)QT * cap * 8))) return rc;
+  uint32_t* d_count = e->d_state;
+  uint32_t* d_hist = d_count + QT;
+  uint32_t* d_shist = d_hist + (size_t)QT * hs;
+  uint32_t* d_tau = d_shist + (size_t)QT * hs;
+
+  const uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(262144, 64ull * k));
+  for (uint32_t q0 = 0; q0 < nq; q0 += QT) {
+    const uint32_t qt = std::min(QT, nq - q0);
+    const uint64_t* dq = d_q + (size_t)q0 * e->W;
+    VC_HIP(e, hipMemsetAsync(e->d_state, 0, state_words * 4, e->stream));
+    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dq, qt, d_shist, hs, e->n_cu, e->stream));
+    VC_HIP(e, vc_launch_tau_init(d_shist, hs, qt, k, e->bits, d_tau, e->stream));
+
+    size_t lds;
+    const VcScanShape sh = vc_scan_pick_shape(e->W, qt, &lds);
+    VcScanParams p{};
+    p.cols = e->d_cols;
+    p.stride = e->stride;
+    p.n = e->n;
+    p.nchunks = (e->n + sh.chunk_items() - 1) / sh.chunk_items();
+    p.id_base = e->cfg.id_base;
+    p.qt = qt;
+    p.k = k;
+    p.cap = cap;
+    p.hist_stride = hs;
+    p.queries = dq;
+    p.tau = d_tau;
+    p.count = d_count;
+    p.hist = d_hist;
+    p.buf = e->d_ring;
+    const uint32_t grid = e->scan_blocks ? e->scan_blocks : e->n_cu * (sh.blk == 256 ? 4u : 2u);
+    hipEvent_t a, b;
+    if ((rc = ev_pair(e, &a, &b))) return rc;
+    VC_HIP(e, hipEventRecord(a, e->stream));
+    VC_HIP(e, vc_launch_scan(p, e->W, grid, e->stream));
+    VC_HIP(e, hipEventRecord(b, e->stream));
+    e->scan_bytes += e->n * (e->bits / 8);
+    VC_HIP(e, vc_launch_select_ring(e->d_ring, cap, d_count, qt, k, d_out + (size_t)q0 * k, d_cnt + q0, e->stream));
+    if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + q0, d_count, qt * 4, hipMemcpyDeviceToDevice, e->stream));
+  }
+  return VC_OK;
+}
+
+static int check_knn_args(vc_engine* e, const void* q, uint32_t nq, uint32_t k, uint32_t mode) {
+  if (!e || !q || nq == 0) return VC_ERR_INVALID;
+  if (k == 0 || k > VC_MAX_K) return fail(e, VC_ERR_INVALID, "k must be in 1..%u", VC_MAX_K);
+  if (mode > VC_MODE_MIH_APPROX) return fail(e, VC_ERR_INVALID, "unknown mode %u", mode);
+  if (mode != VC_MODE_LINEAR && !e->mih) return fail(e, VC_ERR_STATE, "MIH search needs vc_build_index() first (n_tables=%u)", e->m);
+  return VC_OK;
+}
+
+int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode, uint64_t* d_out,
+                      uint32_t* d_counts, void* stream) {
+  int rc = check_knn_args(e, d_queries, nq, k, mode);
+  if (rc) return rc;
+  if (!d_out) return VC_ERR_INVALID;
+  if ((rc = bind_device(e))) return rc;
+  hipStream_t saved = e->stream;
+  if (stream) e->stream = (hipStream_t)stream;
+  if ((rc = grow(e, &e->d_cnt, &e->cnt_bytes, (size_t)nq * 8))) { e->stream = saved; return rc; }
+  timing_begin(e);
+  if (mode == VC_MODE_LINEAR) {
+    rc = linear_batch(e, (const uint64_t*)d_queries, nq, k, d_out, d_counts ? d_counts : e->d_cnt, nullptr);
+  } else {
+    rc = vc_mih_search(e->mih, e->d_cols, e->stride, e->n, (const uint64_t*)d_queries, nq, k, mode == VC_MODE_MIH_APPROX,
+                       d_out, d_counts ? d_counts : e->d_cnt, nullptr, e->stream, &e->err);
+  }
+  timing_end(e);
+  e->stream = saved;
+  return rc;
+}
+
+int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, uint32_t mode, uint32_t order,
+                  uint64_t* out, uint32_t* counts, vc_query_stats* stats) {
+  int rc = check_knn_args(e, queries, nq, k, mode);
+  if (rc) return rc;
+  if (!out || order > VC_ORDER_FARTHEST_FIRST) return VC_ERR_INVALID;
+  if ((rc = bind_device(e))) return rc;
+  const size_t qbytes = (size_t)nq * (e->bits / 8);
+  if ((rc = grow(e, &e->d_q, &e->q_bytes, qbytes))) return rc;
+  if ((rc = grow(e, &e->d_out, &e->out_bytes, (size_t)nq * k * 8))) return rc;
+  if ((rc = grow(e, &e->d_cnt, &e->cnt_bytes, (size_t)nq * 8))) return rc;
+  VC_HIP(e, hipMemcpyAsync(e->d_q, queries, qbytes, hipMemcpyHostToDevice, e->stream));
+  std::vector<uint32_t> cnt(2 * (size_t)nq, 0);
+  std::vector<vc_query_stats> st;
+  timing_begin(e);
+  if (mode == VC_MODE_LINEAR) {
+    rc = linear_batch(e, e->d_q, nq, k, e->d_out, e->d_cnt, e->d_cnt + nq);
+  } else {
+    st.resize(nq);
+    rc = vc_mih_search(e->mih, e->d_cols, e->stride, e->n, e->d_q, nq, k, mode == VC_MODE_MIH_APPROX, e->d_out,
+                       e->d_cnt, st.data(), e->stream, &e->err);
+  }
+  timing_end(e);
+  if (rc) return rc;
+  VC_HIP(e, hipMemcpyAsync(out, e->d_out, (size_t)nq * k * 8, hipMemcpyDeviceToHost, e->stream));
+  VC_HIP(e, hipMemcpyAsync(cnt.data(), e->d_cnt, (mode == VC_MODE_LINEAR ? 2 : 1) * (size_t)nq * 4, hipMemcpyDeviceToHost, e->stream));
+  VC_HIP(e, hipStreamSynchronize(e->stream));
+  if (mode == VC_MODE_LINEAR) {
+    const uint32_t cap = std::max(e->cap, 4 * k);
+    for (uint32_t i = 0; i < nq; ++i)
+      if (cnt[nq + i] > cap)
+        return fail(e, VC_ERR_CAPACITY, "query %u: %u candidates tie at or below the k-th distance, ring holds %u (raise vc_config.cand_cap)", i, cnt[nq + i], cap);
+  }
+  for (uint32_t i = 0; i < nq; ++i) {
+    if (order == VC_ORDER_FARTHEST_FIRST) std::reverse(out + (size_t)i * k, out + (size_t)i * k + cnt[i]);
+    if (counts) counts[i] = cnt[i];
+    if (stats) {
+      if (mode == VC_MODE_LINEAR) {
+        memset(&stats[i], 0, sizeof stats[i]);
+        stats[i].n_candidates = e->n;
+      } else {
+        stats[i] = st[i];
+      }
+      stats[i].n_results = cnt[i];
+    }
+  }
+  return VC_OK;
+}
+
+int vc_merge_topk_dev(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* d_out,
+                      uint32_t* d_counts, void* stream) {
+  if (!d_lists || !d_out || n_lists == 0 || nq == 0 || k == 0 || k > VC_MAX_K) return VC_ERR_INVALID;
+  hipError_t r = vc_launch_select_lists(d_lists, n_lists, nq, k, d_out, d_counts, (hipStream_t)stream);
+  if (r != hipSuccess) return fail(nullptr, VC_ERR_HIP, "merge launch: %s", hipGetErrorString(r));
+  return VC_OK;
+}
+
+// ---- MIH index / bucket views -----------------------------------------------------------------------
+int vc_build_index(vc_engine* e) {
+  if (!e) return VC_ERR_INVALID;
+  if (e->m == 0) return fail(e, VC_ERR_STATE, "engine was created with n_tables = 0 (linear only)");
+  int rc = bind_device(e);
+  if (rc) return rc;
+  if (e->mih) { vc_mih_free(e->mih); e->mih = nullptr; }
+  return vc_mih_build(&e->mih, e->d_cols, e->stride, e->n, e->W, e->m, e->sbits, e->cfg.id_base, e->cfg.flags, e->n_cu,
+                      e->cap, e->stream, &e->err);
+}
+
+int vc_get_bucket(vc_engine* e, uint32_t table, uint32_t index, uint32_t* ids, void* codes, uint32_t cap, uint32_t* n) {
+  if (!e || !n) return VC_ERR_INVALID;
+  if (!e->mih) return fail(e, VC_ERR_STATE, "no index built");
+  if (table >= e->m) return fail(e, VC_ERR_INVALID, "table %u >= n_tables %u", table, e->m);
+  int rc = bind_device(e);
+  if (rc) return rc;
+  std::vector<uint32_t> local;
+  rc = vc_mih_bucket(e->mih, table, index, &local, e->stream, &e->err);
+  if (rc < 0) return rc;
+  *n = (uint32_t)local.size();
+  if (local.empty()) return VC_NOT_FOUND;
+  const uint32_t take = std::min<uint32_t>(cap, (uint32_t)local.size());
+  if (codes && take) {
+    const size_t rec = e->bits / 8;
+    if ((rc = grow(e, (uint8_t**)&e->d_stage, &e->stage_bytes, take * (rec + 4)))) return rc;
+    uint32_t* d_ids = (uint32_t*)((uint8_t*)e->d_stage + (size_t)take * rec);
+    VC_HIP(e, hipMemcpyAsync(d_ids, local.data(), take * 4, hipMemcpyHostToDevice, e->stream));
+    VC_HIP(e, vc_launch_gather_rows(e->d_cols, e->stride, e->W, d_ids, take, (uint64_t*)e->d_stage, e->stream));
+    VC_HIP(e, hipMemcpyAsync(codes, e->d_stage, take * rec, hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(e, hipStreamSynchronize(e->stream));
+  }
+  if (ids)
+    for (uint32_t i = 0; i < take; ++i) ids[i] = e->cfg.id_base + local[i];
+  return VC_OK;
+}
+
+int vc_bitmap_test(vc_engine* e, uint32_t table, uint32_t index, int* bit) {
+  if (!e || !bit) return VC_ERR_INVALID;
+  if (!e->mih) return fail(e, VC_ERR_STATE, "no index built");
+  if (table >= e->m) return VC_ERR_INVALID;
+  int rc = bind_device(e);
+  if (rc) return rc;
+  return vc_mih_bitmap_test(e->mih, table, index, bit, e->stream, &e->err);
+}
+
+int vc_bitmap_read(vc_engine* e, uint32_t table, uint64_t word_off, uint64_t n_words, uint32_t* out) {
+  if (!e || !out) return VC_ERR_INVALID;
+  if (!e->mih) return fail(e, VC_ERR_STATE, "no index built");
+  if (table >= e->m) return VC_ERR_INVALID;
+  int rc = bind_device(e);
+  if (rc) return rc;
+  return vc_mih_bitmap_read(e->mih, table, word_off, n_words, out, e->stream, &e->err);
+}
+
+int vc_search_radius(vc_engine* e, const void* queries, uint32_t nq, uint32_t radius, uint32_t mode, uint64_t* out,
+                     uint64_t out_cap, uint64_t* out_offsets) {
+  if (!e || !queries || !out_offsets || nq == 0) return VC_ERR_INVALID;
+  if (mode != VC_MODE_LINEAR && mode != VC_MODE_MIH_EXACT) return fail(e, VC_ERR_INVALID, "radius search: mode must be LINEAR or MIH_EXACT");
+  if (mode == VC_MODE_MIH_EXACT && !e->mih) return fail(e, VC_ERR_STATE, "MIH search needs vc_build_index() first");
+  int rc = bind_device(e);
+  if (rc) return rc;
+  const size_t qbytes = (size_t)nq * (e->bits / 8);
+  if ((rc = grow(e, &e->d_q, &e->q_bytes, qbytes))) return rc;
+  VC_HIP(e, hipMemcpyAsync(e->d_q, queries, qbytes, hipMemcpyHostToDevice, e->stream));
+  timing_begin(e);
+  rc = vc_radius_search(e->mih, mode == VC_MODE_MIH_EXACT, e->d_cols, e->stride, e->n, e->W, e->cfg.id_base, e->n_cu,
+                        e->d_q, nq, radius, out, out_cap, out_offsets, e->stream, &e->err);
+  timing_end(e);
+  return rc;
+}
+
+}  // extern "C"

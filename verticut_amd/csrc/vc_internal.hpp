@@ -1,0 +1,32 @@
+// Host-side launcher declarations shared by the translation units of libverticut_gpu.so.
+#pragma once
+#include "vc_common.hpp"
+
+// ---- vc_scan.hip ------------------------------------------------------------------------------
+// Scan-kernel shape chosen per call: BLK threads, U column loads per thread per chunk.
+struct VcScanShape {
+  int blk;      // 256 or 512
+  int unroll;   // U
+  uint64_t chunk_items() const { return 2ull * blk * unroll; }
+};
+VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes);
+
+hipError_t vc_launch_fill_synth(uint64_t* cols, uint64_t stride, uint32_t W, uint64_t first_local, uint64_t n,
+                                uint64_t first_gid, uint64_t seed, uint32_t kind, uint32_t n_centres,
+                                uint32_t max_flips, hipStream_t s);
+hipError_t vc_launch_rows_to_cols(const uint64_t* rows, uint64_t* cols, uint64_t stride, uint32_t W,
+                                  uint64_t first_local, uint64_t n, hipStream_t s);
+hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t W, const uint32_t* d_local_ids,
+                                 uint32_t n_ids, uint64_t* d_rows, hipStream_t s);
+hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
+                                 const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
+                                 uint32_t n_cu, hipStream_t s);
+hipError_t vc_launch_tau_init(const uint32_t* d_shist, uint32_t hist_stride, uint32_t qt, uint32_t k, uint32_t bits,
+                              uint32_t* d_tau, hipStream_t s);
+hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t grid_blocks, hipStream_t s);
+// ring -> sorted top-k (per query); out padded with VC_PACK_INF
+hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, uint32_t nq, uint32_t k,
+                                 uint64_t* d_out, uint32_t* d_out_count, hipStream_t s);
+// n_lists x [nq][k] sorted lists -> merged top-k
+hipError_t vc_launch_select_lists(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* d_out,
+                                  uint32_t* d_out_count, hipStream_t s);

@@ -1,0 +1,23 @@
+// Multi-index-hashing side of the engine (vc_mih.hip): index build, bucket views, radius-incremental search.
+#pragma once
+#include "vc_common.hpp"
+
+struct VcMihIndex;
+
+int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t m,
+                 uint32_t sbits, uint32_t id_base, uint32_t flags, uint32_t n_cu, uint32_t cand_cap, hipStream_t s,
+                 std::string* err);
+void vc_mih_free(VcMihIndex* ix);
+// d_q [nq][W]; d_out [nq][k] ascending INF-padded; d_cnt [nq]; stats (host, may be null) filled after a sync.
+int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint64_t n, const uint64_t* d_q, uint32_t nq,
+                  uint32_t k, bool approximate, uint64_t* d_out, uint32_t* d_cnt, vc_query_stats* stats, hipStream_t s,
+                  std::string* err);
+int vc_mih_bucket(VcMihIndex* ix, uint32_t table, uint32_t index, std::vector<uint32_t>* local_ids, hipStream_t s,
+                  std::string* err);
+int vc_mih_bitmap_test(VcMihIndex* ix, uint32_t table, uint32_t index, int* bit, hipStream_t s, std::string* err);
+int vc_mih_bitmap_read(VcMihIndex* ix, uint32_t table, uint64_t word_off, uint64_t n_words, uint32_t* out, hipStream_t s,
+                       std::string* err);
+// all items within full distance <= radius; ix may be null when use_mih is false (linear scan)
+int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W,
+                     uint32_t id_base, uint32_t n_cu, const uint64_t* d_q, uint32_t nq, uint32_t radius, uint64_t* out,
+                     uint64_t out_cap, uint64_t* out_offsets, hipStream_t s, std::string* err);

@@ -1,0 +1,576 @@
+// ============================================================================
+// vc_scan.hip -- the verify path: full-code XOR/popcount over packed uint64 code columns,
+// threshold filter, wavefront ballot/prefix-sum compaction, top-k select.   gfx950 only.
+//
+// Replaces (reference, CPU):
+//   Pilaf/image_tools.h:21-33      compute_hamming_dist  -> vc_dist<W>()
+//   src/linear_search.cc:44-57     scan + max-heap(k)    -> vc_scan_kernel + vc_select_kernel
+//   src/search_worker.cc:249-257   candidate verify+pack -> same device functions (vc_mih.hip)
+//   src/search_worker.cc:179-199   master-side heap      -> vc_select_kernel (ring or gathered lists)
+//
+// Roofline: HBM read.  Algorithmic bytes per launch of vc_scan_kernel = N * B/8 (every code
+// byte exactly once per query tile); integer work = qt * N * (B/32 xor + B/32 v_bcnt + ~1).
+// ============================================================================
+#include "vc_internal.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// data-movement kernels
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vc_fill_synth_kernel(uint64_t* __restrict__ cols, uint64_t stride, uint32_t W,
+                                                            uint64_t first_local, uint64_t n, uint64_t first_gid,
+                                                            uint64_t seed, uint32_t kind, uint32_t n_centres,
+                                                            uint32_t max_flips) {
+  const uint64_t sm = vc_mix64(seed);
+  const uint64_t cm = vc_mix64(seed ^ VC_SALT_CENTRE);
+  const uint64_t im = vc_mix64(seed ^ VC_SALT_ITEM);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t gid = first_gid + i;
+    uint64_t w[VC_MAX_W];
+    if (kind == VC_SYNTH_UNIFORM) {
+      for (uint32_t j = 0; j < W; ++j) w[j] = vc_mix64(sm ^ (gid * 16 + j));
+    } else {
+      const uint64_t r0 = vc_mix64(im ^ gid);
+      const uint64_t c = r0 % n_centres;
+      const uint32_t nflips = (uint32_t)((r0 >> 32) % (max_flips + 1));
+      for (uint32_t j = 0; j < W; ++j) w[j] = vc_mix64(cm ^ (c * 16 + j));
+      for (uint32_t t = 0; t < nflips; ++t) {
+        const uint32_t pos = (uint32_t)(vc_mix64(r0 + t + 1) % (64u * W));
+        for (uint32_t j = 0; j < W; ++j)
+          if (j == (pos >> 6)) w[j] ^= 1ull << (pos & 63);
+      }
+    }
+    for (uint32_t j = 0; j < W; ++j) cols[j * stride + first_local + i] = w[j];
+  }
+}
+
+// row-major records (as in the reference's code file, build_hash_tables.cc:42) -> uint64 columns
+__global__ void __launch_bounds__(256) vc_rows_to_cols_kernel(const uint64_t* __restrict__ rows,
+                                                              uint64_t* __restrict__ cols, uint64_t stride, uint32_t W,
+                                                              uint64_t first_local, uint64_t n) {
+  const uint64_t total = n * W;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = e / W;
+    const uint32_t j = (uint32_t)(e % W);
+    cols[j * stride + first_local + i] = rows[e];
+  }
+}
+
+__global__ void __launch_bounds__(256) vc_gather_rows_kernel(const uint64_t* __restrict__ cols, uint64_t stride,
+                                                             uint32_t W, const uint32_t* __restrict__ ids,
+                                                             uint32_t n_ids, uint64_t* __restrict__ rows) {
+  const uint32_t total = n_ids * W;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const uint32_t i = e / W, j = e % W;
+    rows[e] = cols[j * stride + ids[i]];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Hamming distance of one item (W uint64 words held in registers) to a query.
+// hipcc lowers each 64-bit popcount to two v_bcnt_u32_b32 with the running sum as accumulator.
+// ------------------------------------------------------------------------------------------
+// v_bcnt_u32_b32 d, x, acc  ==  popcount(x) + acc.  Spelled as asm so the four (eight, ...) word counts of a
+// code stay ONE accumulate chain: left to itself hipcc forms two half chains and spends a v_add3 per item.
+__device__ __forceinline__ uint32_t vc_bcnt_acc(uint32_t x, uint32_t acc) {
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ uint32_t vc_bcnt0(uint32_t x) {
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
+  return r;
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t vc_dist(const uint64_t (&c)[W], const uint64_t (&q)[W]) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {  // one accumulating v_bcnt_u32_b32 per 32-bit half, single dependency chain
+    const uint64_t x = c[j] ^ q[j];
+    d = (uint32_t)__builtin_popcount((uint32_t)x) + d;
+    d = (uint32_t)__builtin_popcount((uint32_t)(x >> 32)) + d;
+  }
+  return d;
+}
+
+// ------------------------------------------------------------------------------------------
+// Threshold bootstrap: exact distance histogram of the first s_items codes, per query.
+// One LDS histogram per (block, query sub-tile); flushed with one global atomic per non-empty bin.
+// ------------------------------------------------------------------------------------------
+#define VC_SAMPLE_QSUB 32
+
+template <int W>
+__global__ void __launch_bounds__(256) vc_sample_hist_kernel(const uint64_t* __restrict__ cols, uint64_t stride,
+                                                             uint64_t s_items, const uint64_t* __restrict__ queries,
+                                                             uint32_t qt, uint32_t* __restrict__ shist, uint32_t hs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t q0 = blockIdx.y * VC_SAMPLE_QSUB;
+  const uint32_t nq = min((uint32_t)VC_SAMPLE_QSUB, qt - q0);
+  uint64_t* sq = (uint64_t*)smem;                                      // [nq][W]
+  uint32_t* lh = (uint32_t*)(smem + (size_t)VC_SAMPLE_QSUB * W * 8);   // [nq][hs]
+  for (uint32_t i = threadIdx.x; i < nq * W; i += blockDim.x) sq[i] = queries[(uint64_t)q0 * W + i];
+  for (uint32_t i = threadIdx.x; i < nq * hs; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+
+  const uint64_t npairs = (s_items + 1) / 2;
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t a[W], b[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const vc_u64x2 v = *reinterpret_cast<const vc_u64x2*>(cols + j * stride + 2 * p);
+      a[j] = v.x;
+      b[j] = v.y;
+    }
+    const bool vb = (2 * p + 1) < s_items;
+    for (uint32_t q = 0; q < nq; ++q) {
+      uint64_t qw[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
+      atomicAdd(&lh[q * hs + vc_dist<W>(a, qw)], 1u);
+      if (vb) atomicAdd(&lh[q * hs + vc_dist<W>(b, qw)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nq * hs; i += blockDim.x) {
+    const uint32_t c = lh[i];
+    if (c) atomicAdd(&shist[(uint64_t)q0 * hs + i], c);
+  }
+}
+
+// tau[q] = smallest d with  sum_{d' <= d} hist[q][d'] >= k ;  bits (accept everything) if none.
+// One wave per query.
+__device__ __forceinline__ uint32_t vc_hist_cut(const uint32_t* h, uint32_t nbins, uint32_t k, bool atomic_reads) {
+  const uint32_t lane = vc_lane();
+  const uint32_t bpl = (nbins + VC_WAVE - 1) / VC_WAVE;  // consecutive bins per lane
+  uint32_t mine = 0;
+  for (uint32_t i = 0; i < bpl; ++i) {
+    const uint32_t bin = lane * bpl + i;
+    if (bin < nbins) mine += atomic_reads ? vc_ld_relaxed(h + bin) : h[bin];
+  }
+  uint32_t total;
+  uint32_t run = vc_wave_excl_scan(mine, total);
+  uint32_t cand = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < bpl; ++i) {
+    const uint32_t bin = lane * bpl + i;
+    if (bin < nbins) {
+      run += atomic_reads ? vc_ld_relaxed(h + bin) : h[bin];
+      if (run >= k && cand == 0xFFFFFFFFu) cand = bin;
+    }
+  }
+  return vc_wave_min(cand);
+}
+
+__global__ void __launch_bounds__(64) vc_tau_init_kernel(const uint32_t* __restrict__ shist, uint32_t hs, uint32_t k,
+                                                         uint32_t bits, uint32_t* __restrict__ tau) {
+  const uint32_t q = blockIdx.x;
+  const uint32_t cut = vc_hist_cut(shist + (uint64_t)q * hs, bits + 1, k, false);
+  if (threadIdx.x == 0) tau[q] = (cut == 0xFFFFFFFFu) ? bits : cut;
+}
+
+// ------------------------------------------------------------------------------------------
+// THE verify kernel.
+//
+// Layout: word j of item i at cols[j*stride + i].  A lane owns the item pair (2p, 2p+1) and reads
+// it with one 16-byte load per column, so every wave-instruction fetches 1 KiB contiguous.
+// A block walks chunks of 2*BLK*U items grid-strided; the next chunk's loads are issued before the
+// current chunk is verified (register double buffer), so HBM requests stay in flight under the VALU work.
+//
+// Query tile: staged once per block in LDS ([qt][W] words + [qt] thresholds) and streamed with
+// wave-uniform (broadcast) ds_reads against the register-resident code tile -- the DB is read once
+// per tile whatever qt is.
+//
+// Filter: per query a distance threshold tau (k-th best distance known so far, chip-wide).  Hot loop =
+// xor, v_bcnt accumulate, min, one compare per query.  Rare path (a lane beat tau): refresh tau from
+// HBM, ballot + prefix-sum the survivors of the wave, reserve ring space with ONE atomic per wave,
+// store packed dist<<32|id (search_worker.cc:254-256), bump the chip-wide distance histogram and
+// re-derive tau from it (smallest d whose cumulative count reaches k).  tau only ever decreases and a
+// stale tau is merely conservative, so no ordering between waves is needed for correctness.
+// ------------------------------------------------------------------------------------------
+template <int W, int U, int BLK>
+__device__ __forceinline__ void vc_scan_slow(const VcScanParams& p, const vc_u64x2 (&r)[U][W], const uint64_t (&qw)[W],
+                                             uint32_t q, uint64_t chunk_base, uint32_t* st) {
+  const uint32_t lane = vc_lane();
+  uint32_t t = vc_ld_relaxed(p.tau + q);
+  uint32_t dist[2 * U];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    uint64_t a[W], b[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      a[j] = r[u][j].x;
+      b[j] = r[u][j].y;
+    }
+    const uint64_t ia = chunk_base + (uint64_t)u * 2 * BLK + 2 * threadIdx.x;
+    const uint32_t da = vc_dist<W>(a, qw), db = vc_dist<W>(b, qw);
+    dist[2 * u] = (da <= t && ia < p.n) ? da : 0xFFFFFFFFu;
+    dist[2 * u + 1] = (db <= t && ia + 1 < p.n) ? db : 0xFFFFFFFFu;
+    cnt += (dist[2 * u] != 0xFFFFFFFFu) + (dist[2 * u + 1] != 0xFFFFFFFFu);
+  }
+  if (__ballot(cnt != 0) == 0) {  // tau had already moved below everything this wave holds
+    if (lane == 0) st[q] = t;
+    return;
+  }
+  uint32_t total;
+  uint32_t slot = vc_wave_excl_scan(cnt, total);
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(p.count + q, total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  slot += base;
+  uint64_t* ring = p.buf + (uint64_t)q * p.cap;
+  uint32_t* hist = p.hist + (uint64_t)q * p.hist_stride;
+#pragma unroll
+  for (int e = 0; e < 2 * U; ++e) {
+    if (dist[e] != 0xFFFFFFFFu) {
+      const uint64_t id = chunk_base + (uint64_t)(e >> 1) * 2 * BLK + 2 * threadIdx.x + (e & 1);
+      if (slot < p.cap) ring[slot] = vc_pack(dist[e], p.id_base + (uint32_t)id);
+      ++slot;
+      atomicAdd(hist + dist[e], 1u);
+    }
+  }
+  // re-derive the chip-wide threshold from the histogram of everything appended so far
+  if (base + total >= p.k) {
+    const uint32_t cut = vc_hist_cut(hist, t + 1, p.k, true);
+    if (cut < t) {
+      t = cut;
+      if (lane == 0) atomicMin(p.tau + q, t);
+    }
+  }
+  if (lane == 0) st[q] = t;
+}
+
+template <int W, int U, int BLK>
+__global__ void __launch_bounds__(BLK) vc_scan_kernel(const VcScanParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* sq = (uint64_t*)smem;                             // [qt][W]  query tile
+  uint32_t* st = (uint32_t*)(smem + (size_t)p.qt * W * 8);    // [qt]     block-local copy of tau
+  for (uint32_t i = threadIdx.x; i < p.qt * W; i += BLK) sq[i] = p.queries[i];
+  for (uint32_t i = threadIdx.x; i < p.qt; i += BLK) st[i] = vc_ld_relaxed(p.tau + i);
+  __syncthreads();
+
+  constexpr uint64_t CH = 2ull * BLK * U;
+  vc_u64x2 ra[U][W], rb[U][W];
+
+  auto load = [&](vc_u64x2(&r)[U][W], uint64_t chunk) {
+    const uint64_t base = chunk * CH + 2 * threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        r[u][j] = __builtin_nontemporal_load(
+            reinterpret_cast<const vc_u64x2*>(p.cols + (uint64_t)j * p.stride + base + (uint64_t)u * 2 * BLK));
+  };
+
+  auto verify = [&](const vc_u64x2(&r)[U][W], uint64_t chunk) {
+    for (uint32_t q = 0; q < p.qt; ++q) {
+      uint64_t qw[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
+      const uint32_t t = st[q];
+      uint32_t dmin = 0xFFFFFFFFu;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t da, db;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const uint64_t xa = r[u][j].x ^ qw[j], xb = r[u][j].y ^ qw[j];
+          da = j ? vc_bcnt_acc((uint32_t)xa, da) : vc_bcnt0((uint32_t)xa);
+          da = vc_bcnt_acc((uint32_t)(xa >> 32), da);
+          db = j ? vc_bcnt_acc((uint32_t)xb, db) : vc_bcnt0((uint32_t)xb);
+          db = vc_bcnt_acc((uint32_t)(xb >> 32), db);
+        }
+        dmin = min(dmin, min(da, db));
+      }
+      if (__ballot(dmin <= t) != 0) vc_scan_slow<W, U, BLK>(p, r, qw, q, chunk * CH, st);
+    }
+  };
+
+  uint64_t chunk = blockIdx.x;
+  if (chunk >= p.nchunks) return;
+  load(ra, chunk);
+  // The prefetch is unconditional (past the end it re-reads the block's current chunk, an L2 hit) so the
+  // number of loads in flight is the same on every path and the compiler can wait with a counted vmcnt
+  // for the buffer being verified while the other buffer's loads stay outstanding.
+  for (;;) {
+    uint64_t nx = chunk + gridDim.x;
+    load(rb, nx < p.nchunks ? nx : chunk);
+    verify(ra, chunk);
+    if (nx >= p.nchunks) break;
+    chunk = nx;
+    nx = chunk + gridDim.x;
+    load(ra, nx < p.nchunks ? nx : chunk);
+    verify(rb, chunk);
+    if (nx >= p.nchunks) break;
+    chunk = nx;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Select: the k smallest packed values of a per-query candidate set, ascending.
+// Source = candidate ring of the scan / MIH verify, or the all-gathered per-shard top-k lists
+// (replaces the master-side priority_queue, search_worker.cc:179-199, and
+// mpi_coordinator::gather_vectors' consumer).  One 1024-thread block per query.
+//   n <= 8192 : whole set bitonic-sorted in LDS.
+//   n  > 8192 : 4-pass (11 bit) radix select finds the k-th smallest value, survivors are
+//               compacted into LDS and sorted.
+// ------------------------------------------------------------------------------------------
+struct VcRingSrc {
+  const uint64_t* buf;
+  const uint32_t* count;
+  uint32_t cap;
+  __device__ uint32_t size(uint32_t q) const { return min(count[q], cap); }
+  __device__ uint64_t get(uint32_t q, uint32_t i) const { return buf[(uint64_t)q * cap + i]; }
+};
+struct VcListsSrc {
+  const uint64_t* lists;
+  uint32_t n_lists, nq, k;
+  __device__ uint32_t size(uint32_t) const { return n_lists * k; }
+  __device__ uint64_t get(uint32_t q, uint32_t i) const {
+    return lists[((uint64_t)(i / k) * nq + q) * k + (i % k)];
+  }
+};
+
+#define VC_SEL_THREADS 1024
+
+__device__ __forceinline__ void vc_bitonic_lds(uint64_t* a, uint32_t P) {
+  for (uint32_t size = 2; size <= P; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < (P >> 1); i += VC_SEL_THREADS) {
+        const uint32_t lo = 2 * i - (i & (stride - 1));
+        const uint32_t hi = lo + stride;
+        const uint64_t x = a[lo], y = a[hi];
+        const bool up = (lo & size) == 0;
+        if ((x > y) == up) {
+          a[lo] = y;
+          a[hi] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <class Src>
+__global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint32_t k, uint64_t* __restrict__ out,
+                                                                   uint32_t* __restrict__ out_count) {
+  __shared__ uint64_t a[VC_SORT_CAP];
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t s_prefix_hi, s_prefix_lo, s_rank, s_fill, s_valid;
+  const uint32_t q = blockIdx.x;
+  const uint32_t n = src.size(q);
+  uint32_t P;
+
+  if (n <= VC_SORT_CAP) {
+    P = 1;
+    while (P < n) P <<= 1;
+    if (P < 2) P = 2;
+    for (uint32_t i = threadIdx.x; i < P; i += VC_SEL_THREADS) a[i] = i < n ? src.get(q, i) : VC_PACK_INF;
+  } else {
+    // ---- radix select on the 44 low bits (dist < 2048, id 32 bit); padding (INF) never participates
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
+    uint32_t myvalid = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += VC_SEL_THREADS) myvalid += src.get(q, i) != VC_PACK_INF;
+    atomicAdd(&s_valid, myvalid);
+    __syncthreads();
+    const uint32_t valid = s_valid;
+    uint64_t thresh = VC_PACK_INF - 1;  // valid <= k: keep every valid entry
+    if (valid > k) {
+      if (threadIdx.x == 0) {
+        s_prefix_hi = 0;
+        s_prefix_lo = 0;
+        s_rank = k - 1;  // 0-based rank of the k-th smallest
+      }
+      uint64_t prefix = 0;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 33 - 11 * pass;
+        for (uint32_t i = threadIdx.x; i < 2048; i += VC_SEL_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += VC_SEL_THREADS) {
+          const uint64_t v = src.get(q, i);
+          if (v != VC_PACK_INF && (v >> (shift + 11)) == prefix) atomicAdd(&hist[(uint32_t)(v >> shift) & 0x7FFu], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < VC_WAVE) {  // wave 0 locates the digit holding rank s_rank
+          const uint32_t lane = threadIdx.x;
+          uint32_t mine = 0;
+          for (uint32_t i = 0; i < 32; ++i) mine += hist[lane * 32 + i];
+          uint32_t total;
+          uint32_t run = vc_wave_excl_scan(mine, total);
+          const uint32_t rank = s_rank;
+          uint32_t found = 0xFFFFFFFFu, before = 0;
+          for (uint32_t i = 0; i < 32; ++i) {
+            const uint32_t c = hist[lane * 32 + i];
+            if (found == 0xFFFFFFFFu && rank >= run && rank < run + c) {
+              found = lane * 32 + i;
+              before = run;
+            }
+            run += c;
+          }
+          if (found != 0xFFFFFFFFu) {  // exactly one lane
+            const uint64_t np = (prefix << 11) | found;
+            s_prefix_hi = (uint32_t)(np >> 32);
+            s_prefix_lo = (uint32_t)np;
+            s_rank = rank - before;
+          }
+        }
+        __syncthreads();
+        prefix = ((uint64_t)s_prefix_hi << 32) | s_prefix_lo;
+      }
+      thresh = prefix;  // exact value of the k-th smallest
+    }
+    if (threadIdx.x == 0) s_fill = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += VC_SEL_THREADS) {
+      const uint64_t v = src.get(q, i);
+      if (v <= thresh) {
+        const uint32_t slot = atomicAdd(&s_fill, 1u);
+        if (slot < VC_SORT_CAP) a[slot] = v;
+      }
+    }
+    __syncthreads();
+    const uint32_t fill = min(s_fill, (uint32_t)VC_SORT_CAP);
+    P = 2;
+    while (P < fill) P <<= 1;
+    for (uint32_t i = fill + threadIdx.x; i < P; i += VC_SEL_THREADS) a[i] = VC_PACK_INF;
+  }
+  vc_bitonic_lds(a, P);
+  if (threadIdx.x == 0) s_valid = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  for (uint32_t i = threadIdx.x; i < k; i += VC_SEL_THREADS) {
+    const uint64_t v = i < P ? a[i] : VC_PACK_INF;
+    out[(uint64_t)q * k + i] = v;
+    mine += v != VC_PACK_INF;
+  }
+  if (out_count) {
+    atomicAdd(&s_valid, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) out_count[q] = s_valid;
+  }
+}
+
+template <int W>
+hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t lds, uint32_t grid, hipStream_t s) {
+#define VC_SCAN_CASE(U_, B_)                                                                     \
+  if (sh.unroll == U_ && sh.blk == B_) {                                                         \
+    hipLaunchKernelGGL((vc_scan_kernel<W, U_, B_>), dim3(grid), dim3(B_), lds, s, p);            \
+    return hipGetLastError();                                                                    \
+  }
+  VC_SCAN_CASE(4, 256)
+  VC_SCAN_CASE(2, 256)
+  VC_SCAN_CASE(1, 256)
+  VC_SCAN_CASE(4, 512)
+  VC_SCAN_CASE(2, 512)
+  VC_SCAN_CASE(1, 512)
+#undef VC_SCAN_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------
+VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes) {
+  const size_t lds = (size_t)qt * (W * 8 + 4);
+  if (lds_bytes) *lds_bytes = lds;
+  VcScanShape sh;
+  // 16 B loads in flight per thread per buffer = U*W; keep the two register buffers <= 64 VGPRs each.
+  sh.unroll = W <= 2 ? 4 : (W <= 4 ? 2 : 1);
+  // big LDS tiles leave room for one block per CU only: use 512 threads to keep 2 waves per SIMD.
+  sh.blk = lds > 40 * 1024 ? 512 : 256;
+  return sh;
+}
+
+hipError_t vc_launch_fill_synth(uint64_t* cols, uint64_t stride, uint32_t W, uint64_t first_local, uint64_t n,
+                                uint64_t first_gid, uint64_t seed, uint32_t kind, uint32_t n_centres,
+                                uint32_t max_flips, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(vc_fill_synth_kernel, dim3(grid), dim3(256), 0, s, cols, stride, W, first_local, n, first_gid,
+                     seed, kind, n_centres ? n_centres : 1u, max_flips);
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_rows_to_cols(const uint64_t* rows, uint64_t* cols, uint64_t stride, uint32_t W,
+                                  uint64_t first_local, uint64_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n * W + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(vc_rows_to_cols_kernel, dim3(grid), dim3(256), 0, s, rows, cols, stride, W, first_local, n);
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t W, const uint32_t* d_local_ids,
+                                 uint32_t n_ids, uint64_t* d_rows, hipStream_t s) {
+  if (n_ids == 0) return hipSuccess;
+  const uint32_t grid = std::min<uint32_t>((n_ids * W + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(vc_gather_rows_kernel, dim3(grid), dim3(256), 0, s, cols, stride, W, d_local_ids, n_ids, d_rows);
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
+                                 const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
+                                 uint32_t n_cu, hipStream_t s) {
+  if (s_items == 0 || qt == 0) return hipSuccess;
+  const uint32_t gy = (qt + VC_SAMPLE_QSUB - 1) / VC_SAMPLE_QSUB;
+  const uint64_t npairs = (s_items + 1) / 2;
+  const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * 4);
+  const size_t lds = (size_t)VC_SAMPLE_QSUB * W * 8 + (size_t)VC_SAMPLE_QSUB * hist_stride * 4;
+#define VC_SH_CASE(W_)                                                                                         \
+  case W_:                                                                                                     \
+    hipLaunchKernelGGL((vc_sample_hist_kernel<W_>), dim3(gx, gy), dim3(256), lds, s, cols, stride, s_items,     \
+                       d_queries, qt, d_shist, hist_stride);                                                   \
+    break;
+  switch (W) {
+    VC_SH_CASE(1)
+    VC_SH_CASE(2)
+    VC_SH_CASE(4)
+    VC_SH_CASE(8)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef VC_SH_CASE
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_tau_init(const uint32_t* d_shist, uint32_t hist_stride, uint32_t qt, uint32_t k, uint32_t bits,
+                              uint32_t* d_tau, hipStream_t s) {
+  if (qt == 0) return hipSuccess;
+  hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau);
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t grid_blocks, hipStream_t s) {
+  if (p.nchunks == 0 || p.qt == 0) return hipSuccess;
+  size_t lds;
+  const VcScanShape sh = vc_scan_pick_shape(W, p.qt, &lds);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nchunks, grid_blocks);
+  switch (W) {
+    case 1: return launch_scan_w<1>(p, sh, lds, grid, s);
+    case 2: return launch_scan_w<2>(p, sh, lds, grid, s);
+    case 4: return launch_scan_w<4>(p, sh, lds, grid, s);
+    case 8: return launch_scan_w<8>(p, sh, lds, grid, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, uint32_t nq, uint32_t k,
+                                 uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
+  if (nq == 0) return hipSuccess;
+  VcRingSrc src{d_buf, d_count, cap};
+  hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(nq), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_select_lists(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* d_out,
+                                  uint32_t* d_out_count, hipStream_t s) {
+  if (nq == 0) return hipSuccess;
+  VcListsSrc src{d_lists, n_lists, nq, k};
+  hipLaunchKernelGGL((vc_select_kernel<VcListsSrc>), dim3(nq), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
+  return hipGetLastError();
+}

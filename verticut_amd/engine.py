@@ -1,0 +1,248 @@
+"""ctypes binding of include/verticut_gpu.h -- the only way Python reaches the kernels.
+
+There is no Python or CPU implementation of any search here: if libverticut_gpu.so is missing
+or no gfx950 device is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libverticut_gpu.so")
+
+VC_ABI_VERSION = 1
+VC_OK, VC_NOT_FOUND = 0, 1
+VC_ERR_INVALID, VC_ERR_NO_DEVICE, VC_ERR_HIP, VC_ERR_NOMEM, VC_ERR_STATE, VC_ERR_CAPACITY = -1, -2, -3, -4, -5, -6
+MODE_LINEAR, MODE_MIH_EXACT, MODE_MIH_APPROX = 0, 1, 2
+FLAG_USE_BITMAP, FLAG_REF_SIGNEXT_KEYS, FLAG_REF_STOP_LITERAL4 = 1, 2, 4
+SYNTH_UNIFORM, SYNTH_CLUSTERED = 0, 1
+ORDER_ASCENDING, ORDER_FARTHEST_FIRST = 0, 1
+PACK_INF = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+# every symbol include/verticut_gpu.h declares (tests check the .so exports exactly these)
+EXPORTS = [
+    "vc_create", "vc_destroy", "vc_last_error", "vc_strerror", "vc_abi_version", "vc_add_codes", "vc_add_synthetic",
+    "vc_size", "vc_get_code", "vc_build_index", "vc_get_bucket", "vc_bitmap_test", "vc_bitmap_read", "vc_search_knn",
+    "vc_search_knn_dev", "vc_search_radius", "vc_merge_topk_dev", "vc_get_timing", "vc_set_stream",
+]
+
+
+class VcConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("bits", C.c_uint32), ("n_tables", C.c_uint32), ("flags", C.c_uint32),
+        ("capacity", C.c_uint64), ("id_base", C.c_uint32), ("device", C.c_int32), ("cand_cap", C.c_uint32),
+        ("scan_blocks", C.c_uint32), ("query_tile", C.c_uint32), ("reserved", C.c_uint32 * 5),
+    ]
+
+
+class VcQueryStats(C.Structure):
+    _fields_ = [
+        ("radius", C.c_uint32), ("n_results", C.c_uint32), ("n_main_reads", C.c_uint64), ("n_sub_reads", C.c_uint64),
+        ("n_local_reads", C.c_uint64), ("n_candidates", C.c_uint64),
+    ]
+
+
+class VcTiming(C.Structure):
+    _fields_ = [
+        ("total_ms", C.c_float), ("scan_ms", C.c_float), ("scan_launches", C.c_uint32), ("reserved", C.c_uint32),
+        ("scan_bytes", C.c_uint64),
+    ]
+
+
+class VcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("verticut_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -m verticut_amd.build` (hipcc, gfx950). "
+            "verticut_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.vc_create.argtypes = [C.POINTER(VcConfig), C.POINTER(vp)]
+    L.vc_destroy.argtypes = [vp]
+    L.vc_last_error.restype = C.c_char_p
+    L.vc_last_error.argtypes = [vp]
+    L.vc_strerror.restype = C.c_char_p
+    L.vc_strerror.argtypes = [C.c_int]
+    L.vc_add_codes.argtypes = [vp, vp, u64]
+    L.vc_add_synthetic.argtypes = [vp, u64, u64, u32, u32, u32]
+    L.vc_size.argtypes = [vp, C.POINTER(u64)]
+    L.vc_get_code.argtypes = [vp, u32, vp]
+    L.vc_build_index.argtypes = [vp]
+    L.vc_get_bucket.argtypes = [vp, u32, u32, vp, vp, u32, C.POINTER(u32)]
+    L.vc_bitmap_test.argtypes = [vp, u32, u32, C.POINTER(C.c_int)]
+    L.vc_bitmap_read.argtypes = [vp, u32, u64, u64, vp]
+    L.vc_search_knn.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]
+    L.vc_search_knn_dev.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp]
+    L.vc_search_radius.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp]
+    L.vc_merge_topk_dev.argtypes = [vp, u32, u32, u32, vp, vp, vp]
+    L.vc_get_timing.argtypes = [vp, C.POINTER(VcTiming)]
+    L.vc_set_stream.argtypes = [vp, vp]
+    for name in EXPORTS:
+        if getattr(L, name).restype is not C.c_char_p:
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def split(packed):
+    """packed uint64 -> (ids uint32, dists uint32)  (GET_ID / GET_DIST, search_worker.cc:12-13)."""
+    packed = np.asarray(packed, dtype=np.uint64)
+    return (packed & np.uint64(0xFFFFFFFF)).astype(np.uint32), (packed >> np.uint64(32)).astype(np.uint32)
+
+
+class Engine:
+    """One HBM-resident shard of the code database plus its MIH index (one per GPU/process)."""
+
+    def __init__(self, bits, capacity, n_tables=0, flags=0, id_base=0, device=-1, cand_cap=0, scan_blocks=0,
+                 query_tile=0):
+        self._L = load_library()
+        self.bits, self.nbytes, self.n_tables, self.id_base = bits, bits // 8, n_tables, id_base
+        cfg = VcConfig(abi_version=VC_ABI_VERSION, bits=bits, n_tables=n_tables, flags=flags, capacity=capacity,
+                       id_base=id_base, device=device, cand_cap=cand_cap, scan_blocks=scan_blocks,
+                       query_tile=query_tile)
+        h = C.c_void_p()
+        rc = self._L.vc_create(C.byref(cfg), C.byref(h))
+        if rc != VC_OK:
+            raise VcError(rc, self._L.vc_last_error(None).decode())
+        self._h = h
+
+    # -- plumbing
+    def _check(self, rc, ok=(VC_OK,)):
+        if rc not in ok:
+            raise VcError(rc, self._L.vc_last_error(self._h).decode() or self._L.vc_strerror(rc).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _queries(self, q):
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.nbytes:
+            raise ValueError("query must be %d bytes" % self.nbytes)
+        return q
+
+    # -- ingest
+    def add_codes(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        assert codes.ndim == 2 and codes.shape[1] == self.nbytes
+        self._check(self._L.vc_add_codes(self._h, _p(codes), codes.shape[0]))
+
+    def add_synthetic(self, n, seed, kind=SYNTH_UNIFORM, n_centres=0, max_flips=0):
+        self._check(self._L.vc_add_synthetic(self._h, n, seed, kind, n_centres, max_flips))
+
+    def __len__(self):
+        n = C.c_uint64()
+        self._check(self._L.vc_size(self._h, C.byref(n)))
+        return n.value
+
+    def get_code(self, gid):
+        out = np.empty(self.nbytes, dtype=np.uint8)
+        rc = self._check(self._L.vc_get_code(self._h, gid, _p(out)), ok=(VC_OK, VC_NOT_FOUND))
+        return out if rc == VC_OK else None
+
+    # -- index
+    def build_index(self):
+        self._check(self._L.vc_build_index(self._h))
+
+    def get_bucket(self, table, index, cap=1 << 16, with_codes=True):
+        """BaseProxy.get(HashIndex{table,index}) -> (ids, codes) or None (PROXY_NOT_FOUND)."""
+        ids = np.empty(cap, dtype=np.uint32)
+        codes = np.empty((cap, self.nbytes), dtype=np.uint8) if with_codes else None
+        n = C.c_uint32()
+        rc = self._check(self._L.vc_get_bucket(self._h, table, index, _p(ids), _p(codes) if with_codes else None, cap,
+                                               C.byref(n)), ok=(VC_OK, VC_NOT_FOUND))
+        if rc == VC_NOT_FOUND:
+            return None
+        m = min(n.value, cap)
+        return ids[:m].copy(), (codes[:m].copy() if with_codes else None), n.value
+
+    def bitmap_test(self, table, index):
+        b = C.c_int()
+        self._check(self._L.vc_bitmap_test(self._h, table, index, C.byref(b)))
+        return b.value
+
+    def bitmap_read(self, table, word_off, n_words):
+        out = np.empty(n_words, dtype=np.uint32)
+        self._check(self._L.vc_bitmap_read(self._h, table, word_off, n_words, _p(out)))
+        return out
+
+    # -- search
+    def search_knn(self, queries, k, mode=MODE_LINEAR, order=ORDER_ASCENDING, with_stats=False):
+        """Returns (packed [nq,k] uint64, counts [nq]) (+ list of VcQueryStats)."""
+        q = self._queries(queries)
+        nq = q.shape[0]
+        out = np.full((nq, k), PACK_INF, dtype=np.uint64)
+        counts = np.zeros(nq, dtype=np.uint32)
+        stats = (VcQueryStats * nq)() if with_stats else None
+        self._check(self._L.vc_search_knn(self._h, _p(q), nq, k, mode, order, _p(out), _p(counts),
+                                          C.cast(stats, C.c_void_p) if with_stats else None))
+        if with_stats:
+            return out, counts, list(stats)
+        return out, counts
+
+    def search_knn_dev(self, d_queries, nq, k, d_out, d_counts=None, mode=MODE_LINEAR, stream=None):
+        """Device-pointer variant: arguments are raw device addresses (ints), e.g. tensor.data_ptr()."""
+        self._check(self._L.vc_search_knn_dev(self._h, d_queries, nq, k, mode, d_out, d_counts, stream))
+
+    def search_radius(self, queries, radius, mode=MODE_LINEAR, cap_per_query=4096):
+        q = self._queries(queries)
+        nq = q.shape[0]
+        offs = np.zeros(nq + 1, dtype=np.uint64)
+        cap = nq * cap_per_query
+        for _ in range(2):
+            out = np.empty(max(cap, 1), dtype=np.uint64)
+            rc = self._check(self._L.vc_search_radius(self._h, _p(q), nq, radius, mode, _p(out), cap, _p(offs)),
+                             ok=(VC_OK, VC_ERR_CAPACITY))
+            if rc == VC_OK:
+                return [out[int(offs[i]):int(offs[i + 1])].copy() for i in range(nq)]
+            cap = int(offs[nq])
+        raise VcError(VC_ERR_CAPACITY, "radius search output does not fit")
+
+    def timing(self):
+        t = VcTiming()
+        self._check(self._L.vc_get_timing(self._h, C.byref(t)))
+        return t
+
+    def set_stream(self, stream):
+        self._check(self._L.vc_set_stream(self._h, stream))
+
+
+def merge_topk_dev(d_lists, n_lists, nq, k, d_out, d_counts=None, stream=None):
+    """vc_merge_topk_dev on raw device addresses (replaces gather_vectors + master heap)."""
+    L = load_library()
+    rc = L.vc_merge_topk_dev(d_lists, n_lists, nq, k, d_out, d_counts, stream)
+    if rc != VC_OK:
+        raise VcError(rc, L.vc_last_error(None).decode())
