@@ -1,0 +1,220 @@
+"""GPU parity of the MIH path (search_worker.cc, build_hash_tables.cc, bitmap.cc) against the oracle.
+
+Contract: per query the sorted distance array equals the oracle's, the id set below
+the k-th distance equals the oracle's, ids at the k-th distance are genuine; radius / n_sub_reads /
+n_local_reads equal the oracle's.  On top of that the engine's own canonical rule is checked exactly:
+result == the k smallest (dist, id) among the items whose minimum substring distance is <= radius.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SH = np.uint64(32)
+INF = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _near_queries(codes, nq, rng, max_flips):
+    q = codes[rng.integers(0, codes.shape[0], size=nq)].copy()
+    nb = codes.shape[1]
+    for i in range(nq):
+        for _ in range(rng.integers(0, max_flips + 1)):
+            b = rng.integers(0, nb * 8)
+            q[i, b // 8] ^= np.uint8(1 << (b % 8))
+    return q
+
+
+def _reach_min_subdist(vo, codes, q, m, signext):
+    """min over tables of the substring distance; with sign-extended keys a table only reaches items whose
+    substring top bit equals the query's (Pilaf/image_tools.h:13)."""
+    sub = vo.np_sub_distances(codes, q, m).astype(np.int64)
+    if signext:
+        nlb = codes.shape[1] // m
+        x = np.bitwise_xor(codes, q[None, :]).reshape(codes.shape[0], m, nlb)
+        top_differs = (x[:, :, nlb - 1] & 0x80) != 0
+        sub[top_differs] = 10 ** 6
+    return sub.min(axis=1)
+
+
+def _canonical_mih(vo, codes, q, m, k, radius, signext, id_base=0):
+    seen = _reach_min_subdist(vo, codes, q, m, signext) <= radius
+    d = vo.np_distances(codes, q)
+    ids = np.arange(codes.shape[0], dtype=np.uint64) + np.uint64(id_base)
+    packed = np.sort(vo.pack(d[seen], ids[seen]))
+    return packed[:k], int(seen.sum())
+
+
+def _check_contract(got, oracle_res):
+    """distance multiset + id set below the k-th distance."""
+    o = np.sort(oracle_res)
+    assert len(got) == len(o)
+    assert np.array_equal(got >> SH, o >> SH)
+    if len(o):
+        dk = o[-1] >> SH
+        assert set(got[(got >> SH) < dk].tolist()) == set(o[(o >> SH) < dk].tolist())
+
+
+CONFIGS = [
+    # bits, m, flags-name, n, centres, flips, k
+    (128, 4, "", 60000, 300, 10, 100),       # the reference's native shape: 4 x 32-bit substrings
+    (128, 4, "", 60000, 300, 10, 1),
+    (64, 4, "", 40000, 200, 5, 50),          # 16-bit substrings, masked keys (exact)
+    (64, 4, "signext", 40000, 200, 5, 50),   # 16-bit substrings, binaryToInt sign-extension quirk reproduced
+    (64, 2, "", 40000, 200, 6, 20),          # 2 tables: stop multiplier min(m,4) = 2
+    (64, 2, "literal4", 40000, 200, 6, 20),  # the reference's literal-4 stop rule (may stop early; parity only)
+    (256, 8, "", 30000, 150, 14, 100),       # 8 x 32-bit substrings
+    (64, 8, "", 20000, 100, 4, 10),          # 8-bit substrings
+]
+
+
+@pytest.mark.parametrize("bits,m,fl,n,centres,flips,k", CONFIGS)
+def test_mih_exact_parity(vc, oracle, bits, m, fl, n, centres, flips, k):
+    rng = np.random.default_rng(bits + 31 * m + k)
+    flags = {"": 0, "signext": vc.FLAG_REF_SIGNEXT_KEYS, "literal4": vc.FLAG_REF_STOP_LITERAL4}[fl]
+    signext = fl == "signext"
+    stop_mult = 4 if fl == "literal4" else min(m, 4)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=centres, max_flips=flips)
+    mo = oracle.MihOracle(codes, m, key_mode=0 if signext else 1)
+    q = _near_queries(codes, 12, rng, flips // 2)
+    with vc.Engine(bits, capacity=n, n_tables=m, flags=flags) as e:
+        e.add_synthetic(n, seed=34, kind=1, n_centres=centres, max_flips=flips)
+        e.build_index()
+        got, cnt, stats = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        lin, _ = e.search_knn(q, k, mode=vc.MODE_LINEAR)
+        for i in range(q.shape[0]):
+            ores, ost = mo.find(q[i], k, approximate=False, use_bitmap=False, stop_mult=stop_mult)
+            g = got[i, : cnt[i]]
+            _check_contract(g, ores)
+            assert stats[i].radius == ost.radius, (i, stats[i].radius, ost.radius)
+            assert stats[i].n_sub_reads == ost.n_sub_reads
+            assert stats[i].n_local_reads == 0 and stats[i].n_main_reads == 0
+            assert stats[i].n_candidates == ost.n_distinct
+            exp, _ = _canonical_mih(oracle, codes, q[i], m, k, ost.radius, signext)
+            assert np.array_equal(g, exp)
+            if fl == "":  # exact configurations agree with the linear scan on distances
+                assert np.array_equal(g >> SH, lin[i, : cnt[i]] >> SH)
+
+
+@pytest.mark.parametrize("bits,m,n,k", [(128, 4, 60000, 10), (64, 4, 40000, 10)])
+def test_mih_approximate_parity(vc, oracle, bits, m, n, k):
+    rng = np.random.default_rng(77 + bits)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=100, max_flips=10)
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    q = _near_queries(codes, 8, rng, 3)
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_synthetic(n, seed=34, kind=1, n_centres=100, max_flips=10)
+        e.build_index()
+        got, cnt, stats = e.search_knn(q, k, mode=vc.MODE_MIH_APPROX, with_stats=True)
+        for i in range(q.shape[0]):
+            ores, ost = mo.find(q[i], k, approximate=True, stop_mult=4)
+            g = got[i, : cnt[i]]
+            assert stats[i].radius == ost.radius
+            assert stats[i].n_candidates == ost.n_distinct
+            assert np.array_equal(g >> SH, np.sort(ores) >> SH)
+            exp, _ = _canonical_mih(oracle, codes, q[i], m, k, ost.radius, False)
+            assert np.array_equal(g, exp)
+
+
+def test_mih_bitmap_stats(vc, oracle):
+    """with the bitmap attached (search_worker.cc:238-245): n_local_reads = leaves, n_sub_reads = set bits."""
+    n, bits, m, k = 50000, 128, 4, 20
+    rng = np.random.default_rng(3)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=200, max_flips=8)
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    q = _near_queries(codes, 6, rng, 3)
+    with vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_USE_BITMAP) as e:
+        e.add_codes(codes)
+        e.build_index()
+        got, cnt, stats = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        for i in range(q.shape[0]):
+            ores, ost = mo.find(q[i], k, use_bitmap=True, stop_mult=4)
+            _check_contract(got[i, : cnt[i]], ores)
+            assert (stats[i].radius, stats[i].n_sub_reads, stats[i].n_local_reads) == \
+                (ost.radius, ost.n_sub_reads, ost.n_local_reads)
+
+
+@pytest.mark.parametrize("bits,m,signext", [(128, 4, False), (64, 4, False), (64, 4, True), (64, 8, False)])
+def test_bucket_and_bitmap_views(vc, oracle, bits, m, signext):
+    """HashIndex -> Image_List get (rule a12) and ImageBitmap bits, bucket by bucket."""
+    n = 30000
+    rng = np.random.default_rng(bits + m)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=40, max_flips=3)
+    mo = oracle.MihOracle(codes, m, key_mode=0 if signext else 1, id_base=500)
+    flags = vc.FLAG_REF_SIGNEXT_KEYS if signext else 0
+    with vc.Engine(bits, capacity=n, n_tables=m, flags=flags, id_base=500) as e:
+        e.add_codes(codes)
+        e.build_index()
+        for t in range(m):
+            present = [mo.key(codes[i], t) for i in rng.integers(0, n, size=6)]
+            absent = [int(x) for x in rng.integers(0, 1 << 32, size=4, dtype=np.uint64)]
+            for idx in present + absent:
+                exp = mo.bucket(t, idx)
+                res = e.get_bucket(t, idx, cap=1 << 15)
+                assert e.bitmap_test(t, idx) == (1 if len(exp) else 0)
+                if len(exp) == 0:
+                    assert res is None
+                    continue
+                ids, bcodes, total = res
+                assert total == len(exp) and np.array_equal(ids, exp)
+                assert np.array_equal(bcodes, codes[exp - 500])
+        if bits // m <= 16:  # raw bitmap words as generate_bitmap.cc writes them
+            words = e.bitmap_read(0, 0, (1 << (bits // m)) // 32)
+            keys = {mo.key(codes[i], 0) & ((1 << (bits // m)) - 1) for i in range(n)}
+            exp_words = np.zeros_like(words)
+            for kk in keys:
+                oracle.lib().vco_bitmap_set(exp_words.ctypes.data, kk)
+            assert np.array_equal(words, exp_words)
+
+
+def test_mih_overflow_recovery(vc, oracle):
+    """a shell whose candidates overflow the ring is re-run with a tightened limit; results unchanged."""
+    n, bits, m, k = 80000, 128, 4, 100
+    rng = np.random.default_rng(8)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=8, max_flips=2)  # ~10k items per bucket
+    q = _near_queries(codes, 5, rng, 1)
+    with vc.Engine(bits, capacity=n, n_tables=m, cand_cap=512) as e, vc.Engine(bits, capacity=n, n_tables=m) as big:
+        for eng in (e, big):
+            eng.add_codes(codes)
+            eng.build_index()
+        a, ca, sa = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        b, cb, sb = big.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        assert np.array_equal(a, b) and np.array_equal(ca, cb)
+        for x, y in zip(sa, sb):
+            assert (x.radius, x.n_sub_reads, x.n_candidates) == (y.radius, y.n_sub_reads, y.n_candidates)
+        for i in range(q.shape[0]):
+            exp, _ = _canonical_mih(oracle, codes, q[i], m, k, sa[i].radius, False)
+            assert np.array_equal(a[i, : ca[i]], exp)
+
+
+@pytest.mark.parametrize("bits,m,radius", [(64, 4, 8), (64, 2, 8), (128, 4, 12)])
+def test_radius_search(vc, oracle, bits, m, radius):
+    """BASELINE config 2 shape: all neighbours within full distance r, MIH == linear == numpy."""
+    n = 50000
+    rng = np.random.default_rng(radius + m)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=100, max_flips=6)
+    q = _near_queries(codes, 9, rng, 3)
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        e.build_index()
+        lin = e.search_radius(q, radius, mode=vc.MODE_LINEAR)
+        mih = e.search_radius(q, radius, mode=vc.MODE_MIH_EXACT)
+        for i in range(q.shape[0]):
+            d = oracle.np_distances(codes, q[i])
+            ids = np.nonzero(d <= radius)[0]
+            exp = np.sort(oracle.pack(d[ids], ids.astype(np.uint64)))
+            assert np.array_equal(lin[i], exp)
+            assert np.array_equal(mih[i], exp)
+
+
+def test_mih_needs_index_and_rejects_stale(vc):
+    with vc.Engine(128, capacity=1000, n_tables=4) as e:
+        e.add_synthetic(500, seed=1, kind=vc.SYNTH_CLUSTERED, n_centres=5, max_flips=2)
+        q = e.get_code(0)[None, :]
+        with pytest.raises(vc.VcError) as ei:
+            e.search_knn(q, 5, mode=vc.MODE_MIH_EXACT)
+        assert ei.value.code == vc.VC_ERR_STATE
+        e.build_index()
+        e.search_knn(q, 5, mode=vc.MODE_MIH_EXACT)
+        e.add_synthetic(100, seed=2, kind=vc.SYNTH_CLUSTERED, n_centres=5, max_flips=2)  # invalidates the index
+        with pytest.raises(vc.VcError):
+            e.search_knn(q, 5, mode=vc.MODE_MIH_EXACT)

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters, uint32_t seed
   out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 template <int OP> void run(const char* name, uint32_t* d, int wps) {
-  const int iters = 2000, blocks = 256 * wps / 4 * 1;  // wps waves per SIMD: blocks of 4 waves, 1 per SIMD each
+  const int iters = 2000, blocks = 256 * wps;  // one 4-wave block puts one wave on each SIMD of a CU
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   k<OP><<<blocks, 256>>>(d, 10, 1);
   hipEventRecord(e0); k<OP><<<blocks, 256>>>(d, iters, 1); hipEventRecord(e1); hipEventSynchronize(e1);
@@ -42,7 +42,7 @@ template <int OP> void run(const char* name, uint32_t* d, int wps) {
 }
 int main() {
   uint32_t* d; hipMalloc(&d, 256 * 256 * 8 * 4 * 4);
-  for (int wps : {1, 2, 4}) {
+  for (int wps : {1, 2, 4, 8}) {
     run<0>("v_xor_b32", d, wps); run<1>("v_bcnt_u32_b32", d, wps); run<2>("v_add_u32", d, wps); run<3>("v_sad_u8", d, wps);
     run<4>("v_dot4_u32_u8", d, wps); run<5>("v_dot8_u32_u4", d, wps); run<6>("v_bfi_b32", d, wps); run<7>("v_min3_u32", d, wps);
     run<8>("v_mad_u32_u24", d, wps); run<9>("v_and_or_b32", d, wps); run<10>("v_add3_u32", d, wps); run<11>("v_lshl_add_u32", d, wps);

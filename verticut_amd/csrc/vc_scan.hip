@@ -321,12 +321,15 @@ struct VcRingSrc {
   const uint64_t* buf;
   const uint32_t* count;
   uint32_t cap;
+  const uint32_t* list;   // optional: block b serves ring slot list[b]
+  __device__ uint32_t slot(uint32_t b) const { return list ? list[b] : b; }
   __device__ uint32_t size(uint32_t q) const { return min(count[q], cap); }
   __device__ uint64_t get(uint32_t q, uint32_t i) const { return buf[(uint64_t)q * cap + i]; }
 };
 struct VcListsSrc {
   const uint64_t* lists;
   uint32_t n_lists, nq, k;
+  __device__ uint32_t slot(uint32_t b) const { return b; }
   __device__ uint32_t size(uint32_t) const { return n_lists * k; }
   __device__ uint64_t get(uint32_t q, uint32_t i) const {
     return lists[((uint64_t)(i / k) * nq + q) * k + (i % k)];
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
   __shared__ uint64_t a[VC_SORT_CAP];
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t s_prefix_hi, s_prefix_lo, s_rank, s_fill, s_valid;
-  const uint32_t q = blockIdx.x;
+  const uint32_t q = src.slot(blockIdx.x);
   const uint32_t n = src.size(q);
   uint32_t P;
 
@@ -562,8 +565,16 @@ hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t grid_block
 hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, uint32_t nq, uint32_t k,
                                  uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
   if (nq == 0) return hipSuccess;
-  VcRingSrc src{d_buf, d_count, cap};
+  VcRingSrc src{d_buf, d_count, cap, nullptr};
   hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(nq), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_select_ring_list(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_list,
+                                      uint32_t n_list, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
+  if (n_list == 0) return hipSuccess;
+  VcRingSrc src{d_buf, d_count, cap, d_list};
+  hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(n_list), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
   return hipGetLastError();
 }
 
