@@ -92,13 +92,14 @@ typedef struct vc_query_stats {
   uint64_t n_candidates;  /* distinct DB items verified (owner-rule deduplicated) */
 } vc_query_stats;
 
-/* Timing of the most recent search call, measured with HIP events on the engine's stream. */
+/* Device-side timing of every search call since the previous vc_get_timing(), measured with HIP events
+ * recorded on the stream the kernels were launched on. */
 typedef struct vc_timing {
-  float total_ms;       /* whole call, device side */
-  float scan_ms;        /* sum over launches of the dominant verify kernel */
+  float total_ms;          /* sum over calls of the whole call's device span */
+  float scan_ms;           /* sum over launches of the dominant verify kernel (vc_scan_kernel) */
   uint32_t scan_launches;
-  uint32_t reserved;
-  uint64_t scan_bytes;  /* algorithmic bytes those launches read: passes * N * B/8 */
+  uint32_t calls;
+  uint64_t scan_bytes;     /* algorithmic bytes those launches read: launches * N * B/8 */
 } vc_timing;
 
 /* ---- lifetime ----------------------------------------------------------------------------
@@ -166,6 +167,7 @@ int vc_merge_topk_dev(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, ui
                       uint64_t* d_out, uint32_t* d_counts, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------- */
+/* Sums and resets the event records (synchronises with the last recorded call). */
 int vc_get_timing(const vc_engine* e, vc_timing* t);
 /* Bind the engine's work to a caller-owned stream (hipStream_t); NULL = engine's own stream. */
 int vc_set_stream(vc_engine* e, void* stream);

@@ -25,6 +25,9 @@ def _stale():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps += [os.path.join(HERE, "host", f) for f in ("verticut_host.hpp", "distributed_image_search.cc")]
+    if not os.path.exists(os.path.join(HERE, "bin", "distributed-image-search")):
+        return True
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -50,7 +53,24 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s" % src)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
+    build_host_tools()
     return LIB
+
+
+HOST = os.path.join(HERE, "host")
+BINDIR = os.path.join(HERE, "bin")
+DRIVER = os.path.join(BINDIR, "distributed-image-search")
+
+
+def build_host_tools():
+    """C++ host layer above the C ABI (plain g++): the reference-shaped query driver."""
+    os.makedirs(BINDIR, exist_ok=True)
+    cxx = shutil.which("g++") or "g++"
+    subprocess.check_call([cxx, "-O2", "-std=c++14", "-Wall", "-o", DRIVER,
+                           os.path.join(HOST, "distributed_image_search.cc"), "-I", HOST,
+                           "-L", LIBDIR, "-lverticut_gpu", "-Wl,-rpath,$ORIGIN/../lib",
+                           "-Wl,-rpath-link," + "/opt/rocm/lib", "-L/opt/rocm/lib"])
+    return DRIVER
 
 
 if __name__ == "__main__":

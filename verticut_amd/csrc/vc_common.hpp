@@ -72,7 +72,7 @@ struct VcScanParams {
   uint32_t k;
   uint32_t cap;           // candidate ring entries per query
   uint32_t hist_stride;   // uint32 per query in hist
-  uint32_t pad;
+  uint32_t wrap;          // diagnostic only (VC_SCAN_WRAP): loads wrap onto the first `wrap` chunks (cache-resident)
   const uint64_t* queries;  // [qt][W]
   uint32_t* tau;            // [qt] distance threshold, shared by every wave of the grid
   uint32_t* count;          // [qt] append cursor

@@ -30,11 +30,11 @@ struct vc_engine {
   uint64_t* d_out = nullptr;    size_t out_bytes = 0;     // [nq][k]
   uint32_t* d_cnt = nullptr;    size_t cnt_bytes = 0;     // [nq] result counts | [nq] raw ring counts
 
-  // timing
-  std::vector<hipEvent_t> ev;
+  // timing: event pairs recorded since the last vc_get_timing (calls: whole search calls, scans: verify launches)
+  std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
-  bool timing_pending = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_calls, ev_scans;
+  hipEvent_t cur_t0 = nullptr;
   uint64_t scan_bytes = 0;
   vc_timing last{};
 
@@ -142,8 +142,6 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
   int rc = bind_device(e);
   if (rc == VC_OK) {
     hipError_t r = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
-    if (r == hipSuccess) r = hipEventCreate(&e->ev_t0);
-    if (r == hipSuccess) r = hipEventCreate(&e->ev_t1);
     if (r == hipSuccess) r = hipMalloc((void**)&e->d_cols, e->stride * e->W * sizeof(uint64_t));
     if (r == hipSuccess) r = hipMemsetAsync(e->d_cols, 0, e->stride * e->W * sizeof(uint64_t), e->own_stream);
     if (r == hipSuccess) r = hipStreamSynchronize(e->own_stream);
@@ -172,9 +170,7 @@ int vc_destroy(vc_engine* e) {
   (void)hipFree(e->d_ring);
   (void)hipFree(e->d_out);
   (void)hipFree(e->d_cnt);
-  for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-  if (e->ev_t0) (void)hipEventDestroy(e->ev_t0);
-  if (e->ev_t1) (void)hipEventDestroy(e->ev_t1);
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
   return VC_OK;
@@ -240,43 +236,64 @@ int vc_get_code(vc_engine* e, uint32_t id, void* out) {
 }
 
 // ---- timing helpers -----------------------------------------------------------------------------
-static int ev_pair(vc_engine* e, hipEvent_t* a, hipEvent_t* b) {
-  while (e->ev.size() < e->ev_used + 2) {
+// Events live in a grow-only pool and are handed out in pairs; vc_get_timing() sums every pair recorded since
+// the previous vc_get_timing() and recycles them.  Beyond VC_MAX_TIMED pairs recording stops (sums stay valid).
+#define VC_MAX_TIMED 8192
+static hipEvent_t ev_take(vc_engine* e) {
+  if (e->ev_used >= 2 * VC_MAX_TIMED) return nullptr;
+  if (e->ev_used == e->ev_pool.size()) {
     hipEvent_t ev;
-    VC_HIP(e, hipEventCreate(&ev));
-    e->ev.push_back(ev);
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    e->ev_pool.push_back(ev);
   }
-  *a = e->ev[e->ev_used++];
-  *b = e->ev[e->ev_used++];
+  return e->ev_pool[e->ev_used++];
+}
+static int ev_pair(vc_engine* e, hipEvent_t* a, hipEvent_t* b) {
+  *a = ev_take(e);
+  *b = *a ? ev_take(e) : nullptr;
+  if (*a && !*b) { --e->ev_used; *a = nullptr; }
   return VC_OK;
 }
-
 static void timing_begin(vc_engine* e) {
-  e->ev_used = 0;
-  e->scan_bytes = 0;
-  e->timing_pending = true;
-  (void)hipEventRecord(e->ev_t0, e->stream);
+  e->cur_t0 = ev_take(e);
+  if (e->cur_t0) (void)hipEventRecord(e->cur_t0, e->stream);
 }
-static void timing_end(vc_engine* e) { (void)hipEventRecord(e->ev_t1, e->stream); }
+static void timing_end(vc_engine* e) {
+  if (!e->cur_t0) return;
+  hipEvent_t t1 = ev_take(e);
+  if (!t1) { --e->ev_used; e->cur_t0 = nullptr; return; }
+  (void)hipEventRecord(t1, e->stream);
+  e->ev_calls.emplace_back(e->cur_t0, t1);
+  e->cur_t0 = nullptr;
+}
 
 int vc_get_timing(const vc_engine* ce, vc_timing* t) {
   vc_engine* e = const_cast<vc_engine*>(ce);
   if (!e || !t) return VC_ERR_INVALID;
-  if (e->timing_pending) {
+  if (!e->ev_calls.empty() || !e->ev_scans.empty()) {
     int rc = bind_device(e);
     if (rc) return rc;
-    VC_HIP(e, hipEventSynchronize(e->ev_t1));
     vc_timing lt{};
-    (void)hipEventElapsedTime(&lt.total_ms, e->ev_t0, e->ev_t1);
-    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+    for (auto& pr : e->ev_calls) {
       float ms = 0;
-      (void)hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]);
+      VC_HIP(e, hipEventSynchronize(pr.second));
+      (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+      lt.total_ms += ms;
+      lt.calls++;
+    }
+    for (auto& pr : e->ev_scans) {
+      float ms = 0;
+      VC_HIP(e, hipEventSynchronize(pr.second));
+      (void)hipEventElapsedTime(&ms, pr.first, pr.second);
       lt.scan_ms += ms;
       lt.scan_launches++;
     }
     lt.scan_bytes = e->scan_bytes;
     e->last = lt;
-    e->timing_pending = false;
+    e->ev_calls.clear();
+    e->ev_scans.clear();
+    e->ev_used = 0;
+    e->scan_bytes = 0;
   }
   *t = e->last;
   return VC_OK;
@@ -324,13 +341,17 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
     p.count = d_count;
     p.hist = d_hist;
     p.buf = e->d_ring;
+    if (const char* w = getenv("VC_SCAN_WRAP")) p.wrap = (uint32_t)atoi(w);   // diagnostic, results are wrong by design
     const uint32_t grid = e->scan_blocks ? e->scan_blocks : e->n_cu * (sh.blk == 256 ? 4u : 2u);
     hipEvent_t a, b;
-    if ((rc = ev_pair(e, &a, &b))) return rc;
-    VC_HIP(e, hipEventRecord(a, e->stream));
+    ev_pair(e, &a, &b);
+    if (a) VC_HIP(e, hipEventRecord(a, e->stream));
     VC_HIP(e, vc_launch_scan(p, e->W, grid, e->stream));
-    VC_HIP(e, hipEventRecord(b, e->stream));
-    e->scan_bytes += e->n * (e->bits / 8);
+    if (a) {
+      VC_HIP(e, hipEventRecord(b, e->stream));
+      e->ev_scans.emplace_back(a, b);
+      e->scan_bytes += e->n * (e->bits / 8);
+    }
     VC_HIP(e, vc_launch_select_ring(e->d_ring, cap, d_count, qt, k, d_out + (size_t)q0 * k, d_cnt + q0, e->stream));
     if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + q0, d_count, qt * 4, hipMemcpyDeviceToDevice, e->stream));
   }

@@ -7,6 +7,7 @@
 struct VcScanShape {
   int blk;      // 256 or 512
   int unroll;   // U
+  int dbuf;     // register double buffer (prefetch next chunk under the verify) or single buffer + more waves
   uint64_t chunk_items() const { return 2ull * blk * unroll; }
 };
 VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes);

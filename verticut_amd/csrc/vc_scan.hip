@@ -11,6 +11,9 @@
 // Roofline: HBM read.  Algorithmic bytes per launch of vc_scan_kernel = N * B/8 (every code
 // byte exactly once per query tile); integer work = qt * N * (B/32 xor + B/32 v_bcnt + ~1).
 // ============================================================================
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "vc_internal.hpp"
 
 namespace {
@@ -242,7 +245,7 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanParams& p, const vc_u64
   if (lane == 0) st[q] = t;
 }
 
-template <int W, int U, int BLK>
+template <int W, int U, int BLK, bool DB>
 __global__ void __launch_bounds__(BLK) vc_scan_kernel(const VcScanParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* sq = (uint64_t*)smem;                             // [qt][W]  query tile
@@ -255,6 +258,7 @@ __global__ void __launch_bounds__(BLK) vc_scan_kernel(const VcScanParams p) {
   vc_u64x2 ra[U][W], rb[U][W];
 
   auto load = [&](vc_u64x2(&r)[U][W], uint64_t chunk) {
+    if (p.wrap) chunk %= p.wrap;   // diagnostic: keep the stream cache-resident to time the VALU side alone
     const uint64_t base = chunk * CH + 2 * threadIdx.x;
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -264,32 +268,65 @@ __global__ void __launch_bounds__(BLK) vc_scan_kernel(const VcScanParams p) {
             reinterpret_cast<const vc_u64x2*>(p.cols + (uint64_t)j * p.stride + base + (uint64_t)u * 2 * BLK));
   };
 
-  auto verify = [&](const vc_u64x2(&r)[U][W], uint64_t chunk) {
-    for (uint32_t q = 0; q < p.qt; ++q) {
-      uint64_t qw[W];
+  // one query against the register-resident code tile: xor + accumulating v_bcnt per 32-bit word, running min
+  // over the tile's 2*U items, ONE compare + branch per query.
+  auto one_query = [&](const vc_u64x2(&r)[U][W], const uint64_t(&qv)[W], uint32_t t, uint32_t q, uint64_t chunk) {
+    const uint64_t(&qw)[W] = qv;  // VGPR operands: an SGPR source halves the v_xor rate on gfx950 (measured, tools/ubench_bank.hip)
+    // All 2*U items advance in lockstep, one 32-bit word at a time: the 2*U accumulate chains are independent, so
+    // consecutive VALU instructions of a wave never depend on each other (dependency distance 2*U).
+    uint32_t acc[U][2];
 #pragma unroll
-      for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
-      const uint32_t t = st[q];
-      uint32_t dmin = 0xFFFFFFFFu;
+    for (int j = 0; j < W; ++j) {
+      const uint32_t qlo = (uint32_t)qw[j], qhi = (uint32_t)(qw[j] >> 32);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        uint32_t da, db;
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          const uint64_t xa = r[u][j].x ^ qw[j], xb = r[u][j].y ^ qw[j];
-          da = j ? vc_bcnt_acc((uint32_t)xa, da) : vc_bcnt0((uint32_t)xa);
-          da = vc_bcnt_acc((uint32_t)(xa >> 32), da);
-          db = j ? vc_bcnt_acc((uint32_t)xb, db) : vc_bcnt0((uint32_t)xb);
-          db = vc_bcnt_acc((uint32_t)(xb >> 32), db);
-        }
-        dmin = min(dmin, min(da, db));
+        const uint32_t xa = (uint32_t)r[u][j].x ^ qlo, xb = (uint32_t)r[u][j].y ^ qlo;
+        acc[u][0] = j ? vc_bcnt_acc(xa, acc[u][0]) : vc_bcnt0(xa);
+        acc[u][1] = j ? vc_bcnt_acc(xb, acc[u][1]) : vc_bcnt0(xb);
       }
-      if (__ballot(dmin <= t) != 0) vc_scan_slow<W, U, BLK>(p, r, qw, q, chunk * CH, st);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t xa = (uint32_t)(r[u][j].x >> 32) ^ qhi, xb = (uint32_t)(r[u][j].y >> 32) ^ qhi;
+        acc[u][0] = vc_bcnt_acc(xa, acc[u][0]);
+        acc[u][1] = vc_bcnt_acc(xb, acc[u][1]);
+      }
+    }
+    uint32_t dmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < U; ++u) dmin = min(dmin, min(acc[u][0], acc[u][1]));
+    if (__ballot(dmin <= t) != 0) vc_scan_slow<W, U, BLK>(p, r, qw, q, chunk * CH, st);
+  };
+
+  // The query stream is software-pipelined through two register sets: the ds_reads (wave-uniform address =
+  // LDS broadcast) of query q+1 are in flight while query q is verified, so no wave parks on lgkmcnt.
+  auto ldq = [&](uint64_t(&qw)[W], uint32_t& t, uint32_t q) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
+    t = st[q];
+  };
+  auto verify = [&](const vc_u64x2(&r)[U][W], uint64_t chunk) {
+    uint64_t qa[W], qb[W];
+    uint32_t ta, tb;
+    const uint32_t last = p.qt - 1;
+    ldq(qa, ta, 0);
+    for (uint32_t q = 0; q < p.qt; q += 2) {
+      ldq(qb, tb, min(q + 1, last));
+      one_query(r, qa, ta, q, chunk);
+      ldq(qa, ta, min(q + 2, last));
+      if (q + 1 < p.qt) one_query(r, qb, tb, q + 1, chunk);
     }
   };
 
   uint64_t chunk = blockIdx.x;
   if (chunk >= p.nchunks) return;
+  if (!DB) {
+    // single register buffer: memory latency is covered by the other waves of the SIMD (more of them fit)
+    for (; chunk < p.nchunks; chunk += gridDim.x) {
+      load(ra, chunk);
+      verify(ra, chunk);
+    }
+    return;
+  }
   load(ra, chunk);
   // The prefetch is unconditional (past the end it re-reads the block's current chunk, an L2 hit) so the
   // number of loads in flight is the same on every path and the compiler can wait with a counted vmcnt
@@ -461,7 +498,8 @@ template <int W>
 hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t lds, uint32_t grid, hipStream_t s) {
 #define VC_SCAN_CASE(U_, B_)                                                                     \
   if (sh.unroll == U_ && sh.blk == B_) {                                                         \
-    hipLaunchKernelGGL((vc_scan_kernel<W, U_, B_>), dim3(grid), dim3(B_), lds, s, p);            \
+    if (sh.dbuf) hipLaunchKernelGGL((vc_scan_kernel<W, U_, B_, true>), dim3(grid), dim3(B_), lds, s, p);  \
+    else hipLaunchKernelGGL((vc_scan_kernel<W, U_, B_, false>), dim3(grid), dim3(B_), lds, s, p);         \
     return hipGetLastError();                                                                    \
   }
   VC_SCAN_CASE(4, 256)
@@ -487,6 +525,15 @@ VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes) {
   sh.unroll = W <= 2 ? 4 : (W <= 4 ? 2 : 1);
   // big LDS tiles leave room for one block per CU only: use 512 threads to keep 2 waves per SIMD.
   sh.blk = lds > 40 * 1024 ? 512 : 256;
+  sh.dbuf = 1;
+  if (const char* e = getenv("VC_SCAN_SHAPE")) {  // dev knob: "U,BLK,DB"
+    int u = sh.unroll, b = sh.blk, d = sh.dbuf;
+    if (sscanf(e, "%d,%d,%d", &u, &b, &d) >= 1) {
+      if ((u == 1 || u == 2 || u == 4) && u * (int)W <= 8) sh.unroll = u;
+      if (b == 256 || b == 512) sh.blk = b;
+      sh.dbuf = d != 0;
+    }
+  }
   return sh;
 }
 

@@ -45,7 +45,7 @@ class VcQueryStats(C.Structure):
 
 class VcTiming(C.Structure):
     _fields_ = [
-        ("total_ms", C.c_float), ("scan_ms", C.c_float), ("scan_launches", C.c_uint32), ("reserved", C.c_uint32),
+        ("total_ms", C.c_float), ("scan_ms", C.c_float), ("scan_launches", C.c_uint32), ("calls", C.c_uint32),
         ("scan_bytes", C.c_uint64),
     ]
 

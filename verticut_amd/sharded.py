@@ -1,0 +1,112 @@
+"""Database sharded by id range over the GPUs of one node: one process per GPU, per-shard top-k
+exchanged with ONE all-gather (RCCL over xGMI via torch.distributed) and merged on every rank.
+
+Replaces the reference's vertical partition + per-radius MPI_Gather/Gatherv/Bcast
+(search_worker.cc:99-101,177,207; mpi_coordinator.cc:34-69): top-k of a union is the top-k of the per-shard
+top-k's, so the only inter-GPU traffic is nq * k * 8 bytes per rank per batch, and no collective sits
+inside the scan.
+
+torch is plumbing here (device buffers, streams, the process group); all compute goes through the C ABI.
+"""
+import torch
+import torch.distributed as dist
+
+from . import engine as vc
+
+
+def shard_range(total_n, rank, world):
+    """ids [lo, hi) owned by `rank` (contiguous, balanced to within one item)."""
+    return total_n * rank // world, total_n * (rank + 1) // world
+
+
+class GpuBackend:
+    """Local shard search + merge through libverticut_gpu.so."""
+
+    def __init__(self, bits, capacity, id_base, n_tables=0, device=0, **kw):
+        self.engine = vc.Engine(bits, capacity=max(capacity, 1), n_tables=n_tables, id_base=id_base, device=device, **kw)
+        self.device = torch.device("cuda", device)
+
+    def add_synthetic(self, n, seed, kind=vc.SYNTH_UNIFORM, n_centres=0, max_flips=0):
+        self.engine.add_synthetic(n, seed, kind, n_centres, max_flips)
+
+    def add_codes(self, codes):
+        self.engine.add_codes(codes)
+
+    def build_index(self):
+        self.engine.build_index()
+
+    def local_topk(self, queries, k, out, counts, mode):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.engine.search_knn_dev(queries.data_ptr(), queries.shape[0], k, out.data_ptr(), counts.data_ptr(), mode=mode,
+                                   stream=s)
+
+    def merge(self, gathered, world, nq, k, out, counts):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        vc.merge_topk_dev(gathered.data_ptr(), world, nq, k, out.data_ptr(), counts.data_ptr(), stream=s)
+
+    def timing(self):
+        return self.engine.timing()
+
+    def close(self):
+        self.engine.close()
+
+
+class ShardedSearch:
+    """k-NN over a database split across the ranks of `group` (default: WORLD).
+
+    search(queries[nq, bits/8] uint8 on this rank's device, k) -> (packed[nq, k] int64 (bit pattern of the
+    uint64 dist<<32|id, ascending, -1 = padding), counts[nq] int32), identical on every rank.
+    """
+
+    def __init__(self, bits, total_n, rank=None, world=None, n_tables=0, device=None, group=None, backend=None,
+                 **engine_kw):
+        self.group = group
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        self.bits, self.nbytes, self.total_n = bits, bits // 8, total_n
+        self.lo, self.hi = shard_range(total_n, self.rank, self.world)
+        if total_n > 1 << 32:
+            raise ValueError("ids are uint32 (image_search.proto:4): total_n must be <= 2^32")
+        if backend is None:
+            dev = device if device is not None else torch.cuda.current_device()
+            backend = GpuBackend(bits, self.hi - self.lo, self.lo, n_tables=n_tables, device=dev, **engine_kw)
+        self.backend = backend
+        self._buf_key = None
+
+    # -- data
+    def add_synthetic(self, seed, kind=vc.SYNTH_UNIFORM, n_centres=0, max_flips=0):
+        """every rank generates its own id range of the same global database"""
+        self.backend.add_synthetic(self.hi - self.lo, seed, kind, n_centres, max_flips)
+
+    def add_codes_global(self, codes):
+        """codes = the whole database (row-major); this rank keeps rows [lo, hi)"""
+        self.backend.add_codes(codes[self.lo:self.hi])
+
+    def build_index(self):
+        self.backend.build_index()
+
+    # -- search
+    def _buffers(self, nq, k, device):
+        key = (nq, k, str(device))
+        if self._buf_key != key:
+            self._local = torch.empty((nq, k), dtype=torch.int64, device=device)
+            self._lcnt = torch.empty((nq,), dtype=torch.int32, device=device)
+            self._gath = torch.empty((self.world, nq, k), dtype=torch.int64, device=device)
+            self._out = torch.empty((nq, k), dtype=torch.int64, device=device)
+            self._ocnt = torch.empty((nq,), dtype=torch.int32, device=device)
+            self._buf_key = key
+        return self._local, self._lcnt, self._gath, self._out, self._ocnt
+
+    def search(self, queries, k, mode=vc.MODE_LINEAR):
+        nq = queries.shape[0]
+        local, lcnt, gath, out, ocnt = self._buffers(nq, k, queries.device)
+        self.backend.local_topk(queries, k, local, lcnt, mode)
+        if self.world == 1:
+            return local, lcnt
+        # the only exchange step of the path: nq*k*8 bytes per rank
+        dist.all_gather_into_tensor(gath.view(self.world * nq, k), local, group=self.group)  # rank-major concat
+        self.backend.merge(gath, self.world, nq, k, out, ocnt)
+        return out, ocnt
+
+    def close(self):
+        self.backend.close()
