@@ -148,7 +148,9 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
                   uint64_t* out, uint32_t* counts, vc_query_stats* stats);
 /* Device-pointer variant for callers that keep queries/results in HBM (torch / multi-GPU merge).
  * d_queries: nq*bits/8 bytes; d_out: nq*k uint64, ascending, padded with UINT64_MAX; d_counts: nq uint32.
- * Asynchronous on `stream` (a hipStream_t) when mode == VC_MODE_LINEAR; other modes synchronise. */
+ * Asynchronous on `stream` (a hipStream_t) when mode == VC_MODE_LINEAR; other modes synchronise.
+ * LINEAR cannot recover from a candidate-ring overflow without a host round trip: such a query reports
+ * d_counts[i] == UINT32_MAX (its row is then only an upper bound) and should be re-run through vc_search_knn. */
 int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode,
                       uint64_t* d_out, uint32_t* d_counts, void* stream);
 /* All items within full Hamming distance <= radius of each query (BASELINE config 2; built from

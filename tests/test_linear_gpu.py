@@ -97,10 +97,26 @@ def test_many_exact_duplicates(vc, oracle):
         assert np.array_equal(got, exp)
 
 
+def test_ring_overflow_recovery(vc, oracle):
+    """more items at the k-th distance than the candidate ring holds: the scan is repeated with the packed bound
+    of what did fit until nothing overflows; the answer is still the k smallest (dist, id)."""
+    rng = np.random.default_rng(12)
+    base = rng.integers(0, 256, size=(10, 16), dtype=np.uint8)
+    codes = np.repeat(base, 3000, axis=0)          # 30000 items, 3000 copies of each
+    codes = codes[rng.permutation(codes.shape[0])]
+    q = base[:3].copy()
+    q[2, 5] ^= 0x10                                # 3000 ties at distance 1
+    with vc.Engine(128, capacity=codes.shape[0], cand_cap=256) as e:   # ring = max(256, 4k) = 400 entries
+        e.add_codes(codes)
+        got, cnt = e.search_knn(q, 100)
+        exp, ecnt = _expect(oracle, codes, q, 100)
+        assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp)
+
+
 def test_timing_reports_scan(vc):
     with vc.Engine(128, capacity=1 << 20) as e:
         e.add_synthetic(1 << 20, seed=1)
         q = np.zeros((4, 16), dtype=np.uint8)
         e.search_knn(q, 10)
         t = e.timing()
-        assert t.scan_launches == 1 and t.scan_bytes == (1 << 20) * 16 and t.scan_ms > 0
+        assert t.scan_launches == 1 and t.calls == 1 and t.scan_bytes == (1 << 20) * 16 and t.scan_ms > 0

@@ -199,3 +199,24 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle|libvcoracle|libvcref|dlopen\(.*oracle", src, flags=re.M):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+# ----------------------------------------------------------------------------- committed search fixtures
+def test_oracle_reproduces_search_fixtures(oracle):
+    """tests/golden/search_fixtures.json (made by make_search_fixtures.py from the oracle) still holds: guards the
+    generator definition and the loops against drift between the authoring container and any other box."""
+    with open(os.path.join(ROOT, "tests", "golden", "search_fixtures.json")) as f:
+        fxs = json.load(f)["fixtures"]
+    for fx in fxs[:3]:   # the GPU suite covers all of them; keep the CPU suite short
+        codes = oracle.gen_codes(fx["n"], fx["bits"], fx["seed"], fx["kind"], fx["n_centres"], fx["max_flips"])
+        for i, qh in enumerate(fx["queries"]):
+            q = np.frombuffer(bytes.fromhex(qh), dtype=np.uint8)
+            assert [int(v) for v in oracle.linear_knn(codes, q, fx["k"])] == fx["linear"][i]
+        if fx["mih_exact"]:
+            mo = oracle.MihOracle(codes, fx["m"], key_mode=1)
+            for i, qh in enumerate(fx["queries"]):
+                q = np.frombuffer(bytes.fromhex(qh), dtype=np.uint8)
+                res, st = mo.find(q, fx["k"], stop_mult=min(fx["m"], 4))
+                e = fx["mih_exact"][i]
+                assert (st.radius, st.n_sub_reads, st.n_distinct) == (e["radius"], e["n_sub_reads"], e["n_candidates"])
+                assert sorted(int(v) >> 32 for v in res) == [v >> 32 for v in e["result"]]

@@ -1,0 +1,55 @@
+"""Multi-rank path on the one GPU of the test box: two processes share cuda:0, each owns half of the id range
+(real engines, real merge kernel); the exchange goes over gloo because RCCL wants one device per rank.  The
+N-GPU RCCL run itself is the driver's; this pins everything around the collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, total_n, bits, k, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import vc_oracle as vo
+    from verticut_amd import engine as vc
+    from verticut_amd.sharded import ShardedSearch
+    ss = ShardedSearch(bits, total_n, rank=rank, world=world, device=0, n_tables=4)
+    ss.add_synthetic(34, kind=vc.SYNTH_CLUSTERED, n_centres=300, max_flips=10)
+    full = vo.gen_codes(total_n, bits, 34, 1, 300, 10)
+    rng = np.random.default_rng(5)
+    q = full[rng.integers(0, total_n, size=9)].copy()
+    q[:, 3] ^= 0x24
+    dq = torch.from_numpy(q).cuda()
+    out, cnt = ss.search(dq, k)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    exp = np.stack([vo.linear_knn(full, q[i], k) for i in range(len(q))])
+    ok = bool(np.array_equal(got, exp) and np.all(cnt.cpu().numpy() == k))
+    # MIH on shards: every shard's exact top-k merged == exact top-k of the union (distances; ties may differ)
+    ss.build_index()
+    out2, _ = ss.search(dq, k, mode=vc.MODE_MIH_EXACT)
+    torch.cuda.synchronize()
+    got2 = out2.cpu().numpy().view(np.uint64)
+    ok = ok and bool(np.array_equal(got2 >> np.uint64(32), exp >> np.uint64(32)))
+    ret[rank] = ok
+    ss.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equals_unsharded():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, 200001, 128, 100, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -41,7 +41,8 @@ def build(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = ["-DVC_SCAN_DIAGNOSTICS=1"] if os.environ.get("VC_BUILD_DIAG") == "1" else []
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

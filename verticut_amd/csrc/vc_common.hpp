@@ -78,4 +78,6 @@ struct VcScanParams {
   uint32_t* count;          // [qt] append cursor
   uint32_t* hist;           // [qt][hist_stride] histogram of appended distances
   uint64_t* buf;            // [qt][cap] appended packed candidates
+  const uint64_t* limit;    // optional [qt]: append only packed values <= limit[q] (ring-overflow recovery)
+  uint32_t diag;            // diagnostic only (VC_SCAN_DIAG): N > 0 replaces the verify arithmetic by s_sleep N per query
 };

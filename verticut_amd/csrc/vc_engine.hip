@@ -300,61 +300,134 @@ int vc_get_timing(const vc_engine* ce, vc_timing* t) {
 }
 
 // ---- LINEAR: linear_search.cc:39-64 for a batch of queries ------------------------------------------
+struct LinearBufs {
+  uint32_t hs, QT, cap;
+  size_t state_words;
+  uint32_t *d_count, *d_hist, *d_shist, *d_tau;
+};
+
+static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
+  b->hs = (e->bits + 1 + 7) & ~7u;
+  b->QT = std::min(e->qtile, nq);
+  b->cap = std::max(e->cap, 4 * k);
+  b->state_words = (size_t)b->QT * (1 + 2 * (size_t)b->hs + 1);
+  int rc;
+  if ((rc = grow(e, &e->d_state, &e->state_bytes, b->state_words * 4))) return rc;
+  if ((rc = grow(e, &e->d_ring, &e->ring_bytes, (size_t)b->QT * b->cap * 8))) return rc;
+  b->d_count = e->d_state;
+  b->d_hist = b->d_count + b->QT;
+  b->d_shist = b->d_hist + (size_t)b->QT * b->hs;
+  b->d_tau = b->d_shist + (size_t)b->QT * b->hs;
+  return VC_OK;
+}
+
+// one verify launch for a tile whose tau is already set; d_limit may be null
+static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint32_t qt, uint32_t k, const uint64_t* d_limit) {
+  const VcScanShape sh = vc_scan_pick_shape(e->W, qt, nullptr);
+  VcScanParams p{};
+  p.cols = e->d_cols;
+  p.stride = e->stride;
+  p.n = e->n;
+  p.nchunks = (e->n + sh.chunk_items() - 1) / sh.chunk_items();
+  p.id_base = e->cfg.id_base;
+  p.qt = qt;
+  p.k = k;
+  p.cap = b.cap;
+  p.hist_stride = b.hs;
+  p.queries = dq;
+  p.tau = b.d_tau;
+  p.count = b.d_count;
+  p.hist = b.d_hist;
+  p.buf = e->d_ring;
+  p.limit = d_limit;
+  if (const char* w = getenv("VC_SCAN_WRAP")) p.wrap = (uint32_t)atoi(w);   // diagnostic, results are wrong by design
+  if (const char* w = getenv("VC_SCAN_DIAG")) p.diag = (uint32_t)atoi(w);   // diagnostic, results are wrong by design
+  hipEvent_t a, bb;
+  ev_pair(e, &a, &bb);
+  if (a) VC_HIP(e, hipEventRecord(a, e->stream));
+  VC_HIP(e, vc_launch_scan(p, e->W, e->n_cu, e->scan_blocks, e->stream));
+  if (a) {
+    VC_HIP(e, hipEventRecord(bb, e->stream));
+    e->ev_scans.emplace_back(a, bb);
+    e->scan_bytes += e->n * (e->bits / 8);
+  }
+  return VC_OK;
+}
+
 // d_q: [nq][W] words on the device.  Results: d_out [nq][k] ascending (INF padded), d_cnt[0..nq) counts,
-// d_cnt[nq..2nq) raw ring counts (overflow detection).
+// d_raw[0..nq) raw ring counts (> cap == the ring overflowed and the row is only an upper bound).
 static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_cnt,
                         uint32_t* d_raw) {
-  const uint32_t hs = (e->bits + 1 + 7) & ~7u;
-  const uint32_t QT = std::min(e->qtile, nq);
-  const uint32_t cap = std::max(e->cap, 4 * k);
-  int rc;
-  const size_t state_words = (size_t)QT * (1 + 2 * (size_t)hs + 1);
-  if ((rc = grow(e, &e->d_state, &e->state_bytes, state_words * 4))) return rc;
-  if ((rc = grow(e, &e->d_ring, &e->ring_bytes, (size_t)QT * cap * 8))) return rc;
-  uint32_t* d_count = e->d_state;
-  uint32_t* d_hist = d_count + QT;
-  uint32_t* d_shist = d_hist + (size_t)QT * hs;
-  uint32_t* d_tau = d_shist + (size_t)QT * hs;
-
+  LinearBufs b;
+  int rc = linear_bufs(e, nq, k, &b);
+  if (rc) return rc;
   const uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(262144, 64ull * k));
-  for (uint32_t q0 = 0; q0 < nq; q0 += QT) {
-    const uint32_t qt = std::min(QT, nq - q0);
+  for (uint32_t q0 = 0; q0 < nq; q0 += b.QT) {
+    const uint32_t qt = std::min(b.QT, nq - q0);
     const uint64_t* dq = d_q + (size_t)q0 * e->W;
-    VC_HIP(e, hipMemsetAsync(e->d_state, 0, state_words * 4, e->stream));
-    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dq, qt, d_shist, hs, e->n_cu, e->stream));
-    VC_HIP(e, vc_launch_tau_init(d_shist, hs, qt, k, e->bits, d_tau, e->stream));
-
-    size_t lds;
-    const VcScanShape sh = vc_scan_pick_shape(e->W, qt, &lds);
-    VcScanParams p{};
-    p.cols = e->d_cols;
-    p.stride = e->stride;
-    p.n = e->n;
-    p.nchunks = (e->n + sh.chunk_items() - 1) / sh.chunk_items();
-    p.id_base = e->cfg.id_base;
-    p.qt = qt;
-    p.k = k;
-    p.cap = cap;
-    p.hist_stride = hs;
-    p.queries = dq;
-    p.tau = d_tau;
-    p.count = d_count;
-    p.hist = d_hist;
-    p.buf = e->d_ring;
-    if (const char* w = getenv("VC_SCAN_WRAP")) p.wrap = (uint32_t)atoi(w);   // diagnostic, results are wrong by design
-    const uint32_t grid = e->scan_blocks ? e->scan_blocks : e->n_cu * (sh.blk == 256 ? 4u : 2u);
-    hipEvent_t a, b;
-    ev_pair(e, &a, &b);
-    if (a) VC_HIP(e, hipEventRecord(a, e->stream));
-    VC_HIP(e, vc_launch_scan(p, e->W, grid, e->stream));
-    if (a) {
-      VC_HIP(e, hipEventRecord(b, e->stream));
-      e->ev_scans.emplace_back(a, b);
-      e->scan_bytes += e->n * (e->bits / 8);
-    }
-    VC_HIP(e, vc_launch_select_ring(e->d_ring, cap, d_count, qt, k, d_out + (size_t)q0 * k, d_cnt + q0, e->stream));
-    if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + q0, d_count, qt * 4, hipMemcpyDeviceToDevice, e->stream));
+    VC_HIP(e, hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
+    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dq, qt, b.d_shist, b.hs, e->n_cu, e->stream));
+    VC_HIP(e, vc_launch_tau_init(b.d_shist, b.hs, qt, k, e->bits, b.d_tau, e->stream));
+    if ((rc = scan_tile(e, b, dq, qt, k, nullptr))) return rc;
+    VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, qt, k, d_out + (size_t)q0 * k, d_cnt + q0, e->stream));
+    if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + q0, b.d_count, qt * 4, hipMemcpyDeviceToDevice, e->stream));
   }
+  return VC_OK;
+}
+
+// Ring-overflow recovery (host-driven, rare: more than `cap` items at or below the k-th distance).  The truncated
+// ring still yields a valid upper bound L on the k-th best packed value; the query is scanned again appending only
+// packed values <= L.  Every round at least quarters the survivors' bound (cap >= 4k distinct values <= L), so it ends.
+static int linear_recover(vc_engine* e, const uint64_t* d_q, uint32_t k, const std::vector<uint32_t>& over,
+                          uint64_t* out /*host [nq][k]*/, uint32_t* cnt /*host [nq]*/) {
+  LinearBufs b;
+  int rc = linear_bufs(e, (uint32_t)over.size(), k, &b);
+  if (rc) return rc;
+  const size_t W = e->W;
+  uint64_t *d_rq = nullptr, *d_lim = nullptr, *d_rout = nullptr;
+  uint32_t* d_rcnt = nullptr;
+  auto cleanup = [&]() { (void)hipFree(d_rq); (void)hipFree(d_lim); (void)hipFree(d_rout); (void)hipFree(d_rcnt); };
+#define RC(call) do { hipError_t _r = (call); if (_r != hipSuccess) { cleanup(); return fail(e, VC_ERR_HIP, "%s: %s", #call, hipGetErrorString(_r)); } } while (0)
+  RC(hipMalloc((void**)&d_rq, b.QT * W * 8));
+  RC(hipMalloc((void**)&d_lim, b.QT * 8));
+  RC(hipMalloc((void**)&d_rout, (size_t)b.QT * k * 8));
+  RC(hipMalloc((void**)&d_rcnt, b.QT * 8));
+  std::vector<uint32_t> todo = over;
+  for (int round = 0; !todo.empty(); ++round) {
+    if (round > 64) { cleanup(); return fail(e, VC_ERR_CAPACITY, "ring overflow recovery did not converge"); }
+    std::vector<uint32_t> next;
+    for (size_t t0 = 0; t0 < todo.size(); t0 += b.QT) {
+      const uint32_t qt = (uint32_t)std::min<size_t>(b.QT, todo.size() - t0);
+      std::vector<uint64_t> lim(qt);
+      std::vector<uint32_t> tau(qt);
+      for (uint32_t i = 0; i < qt; ++i) {
+        const uint32_t q = todo[t0 + i];
+        RC(hipMemcpyAsync(d_rq + i * W, d_q + (size_t)q * W, W * 8, hipMemcpyDeviceToDevice, e->stream));
+        lim[i] = out[(size_t)q * k + k - 1];          // k-th best of what fitted: >= the true k-th best
+        tau[i] = (uint32_t)(lim[i] >> 32);
+      }
+      RC(hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
+      RC(hipMemcpyAsync(d_lim, lim.data(), qt * 8, hipMemcpyHostToDevice, e->stream));
+      RC(hipMemcpyAsync(b.d_tau, tau.data(), qt * 4, hipMemcpyHostToDevice, e->stream));
+      if ((rc = scan_tile(e, b, d_rq, qt, k, d_lim))) { cleanup(); return rc; }
+      RC(vc_launch_select_ring(e->d_ring, b.cap, b.d_count, qt, k, d_rout, d_rcnt, e->stream));
+      std::vector<uint64_t> rout((size_t)qt * k);
+      std::vector<uint32_t> rcnt(qt), raw(qt);
+      RC(hipMemcpyAsync(rout.data(), d_rout, rout.size() * 8, hipMemcpyDeviceToHost, e->stream));
+      RC(hipMemcpyAsync(rcnt.data(), d_rcnt, qt * 4, hipMemcpyDeviceToHost, e->stream));
+      RC(hipMemcpyAsync(raw.data(), b.d_count, qt * 4, hipMemcpyDeviceToHost, e->stream));
+      RC(hipStreamSynchronize(e->stream));
+      for (uint32_t i = 0; i < qt; ++i) {
+        const uint32_t q = todo[t0 + i];
+        memcpy(out + (size_t)q * k, rout.data() + (size_t)i * k, (size_t)k * 8);
+        cnt[q] = rcnt[i];
+        if (raw[i] > b.cap) next.push_back(q);
+      }
+    }
+    todo.swap(next);
+  }
+#undef RC
+  cleanup();
   return VC_OK;
 }
 
@@ -415,9 +488,10 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
   VC_HIP(e, hipStreamSynchronize(e->stream));
   if (mode == VC_MODE_LINEAR) {
     const uint32_t cap = std::max(e->cap, 4 * k);
+    std::vector<uint32_t> over;
     for (uint32_t i = 0; i < nq; ++i)
-      if (cnt[nq + i] > cap)
-        return fail(e, VC_ERR_CAPACITY, "query %u: %u candidates tie at or below the k-th distance, ring holds %u (raise vc_config.cand_cap)", i, cnt[nq + i], cap);
+      if (cnt[nq + i] > cap) over.push_back(i);
+    if (!over.empty() && (rc = linear_recover(e, e->d_q, k, over, out, cnt.data()))) return rc;
   }
   for (uint32_t i = 0; i < nq; ++i) {
     if (order == VC_ORDER_FARTHEST_FIRST) std::reverse(out + (size_t)i * k, out + (size_t)i * k + cnt[i]);

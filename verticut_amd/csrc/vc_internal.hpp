@@ -7,7 +7,7 @@
 struct VcScanShape {
   int blk;      // 256 or 512
   int unroll;   // U
-  int dbuf;     // register double buffer (prefetch next chunk under the verify) or single buffer + more waves
+  int dbuf;     // register buffers per lane: 1 (rely on other waves), 2 (prefetch next chunk), 3 (two chunks ahead)
   uint64_t chunk_items() const { return 2ull * blk * unroll; }
 };
 VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes);
@@ -24,7 +24,8 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
                                  uint32_t n_cu, hipStream_t s);
 hipError_t vc_launch_tau_init(const uint32_t* d_shist, uint32_t hist_stride, uint32_t qt, uint32_t k, uint32_t bits,
                               uint32_t* d_tau, hipStream_t s);
-hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t grid_blocks, hipStream_t s);
+// grid = min(chunks, CUs x resident blocks per CU, want_blocks if non-zero)
+hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, hipStream_t s);
 // ring -> sorted top-k (per query); out padded with VC_PACK_INF
 hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, uint32_t nq, uint32_t k,
                                  uint64_t* d_out, uint32_t* d_out_count, hipStream_t s);

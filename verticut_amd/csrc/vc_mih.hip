@@ -875,7 +875,7 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
         p.id_base = id_base; p.qt = qt; p.k = 0xFFFFFFFFu;   // never re-derive tau: it is the fixed radius
         p.cap = cap; p.hist_stride = hs; p.queries = d_q + (size_t)q0 * W; p.tau = d_tau; p.count = d_count;
         p.hist = d_hist; p.buf = d_ring;
-        R_CHECK(vc_launch_scan(p, W, n_cu * (sh.blk == 256 ? 4u : 2u), s));
+        R_CHECK(vc_launch_scan(p, W, n_cu, 0, s));
       }
       R_CHECK(hipMemcpyAsync(h_count.data(), d_count, qt * 4, hipMemcpyDeviceToHost, s));
       R_CHECK(hipStreamSynchronize(s));

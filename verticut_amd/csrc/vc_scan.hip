@@ -16,6 +16,12 @@
 
 #include "vc_internal.hpp"
 
+// Build with -DVC_SCAN_DIAGNOSTICS=1 (VC_BUILD_DIAG=1 python -m verticut_amd.build) to enable the VC_SCAN_WRAP /
+// VC_SCAN_DIAG study knobs; they cost registers, so the product build leaves them out.
+#ifndef VC_SCAN_DIAGNOSTICS
+#define VC_SCAN_DIAGNOSTICS 0
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -209,8 +215,14 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanParams& p, const vc_u64
     }
     const uint64_t ia = chunk_base + (uint64_t)u * 2 * BLK + 2 * threadIdx.x;
     const uint32_t da = vc_dist<W>(a, qw), db = vc_dist<W>(b, qw);
-    dist[2 * u] = (da <= t && ia < p.n) ? da : 0xFFFFFFFFu;
-    dist[2 * u + 1] = (db <= t && ia + 1 < p.n) ? db : 0xFFFFFFFFu;
+    bool oka = da <= t && ia < p.n, okb = db <= t && ia + 1 < p.n;
+    if (p.limit) {  // recovery pass: exact packed bound, so a flood of ties at the k-th distance cannot refill the ring
+      const uint64_t lim = p.limit[q];
+      oka = oka && vc_pack(da, p.id_base + (uint32_t)ia) <= lim;
+      okb = okb && vc_pack(db, p.id_base + (uint32_t)ia + 1) <= lim;
+    }
+    dist[2 * u] = oka ? da : 0xFFFFFFFFu;
+    dist[2 * u + 1] = okb ? db : 0xFFFFFFFFu;
     cnt += (dist[2 * u] != 0xFFFFFFFFu) + (dist[2 * u + 1] != 0xFFFFFFFFu);
   }
   if (__ballot(cnt != 0) == 0) {  // tau had already moved below everything this wave holds
@@ -245,20 +257,23 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanParams& p, const vc_u64
   if (lane == 0) st[q] = t;
 }
 
-template <int W, int U, int BLK, bool DB>
-__global__ void __launch_bounds__(BLK) vc_scan_kernel(const VcScanParams p) {
+// second launch bound = waves per SIMD the register allocation must leave room for
+template <int W, int U, int BLK, int NB>
+__global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : (NB * U * W > 16 ? 3 : 4))) vc_scan_kernel(const VcScanParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* sq = (uint64_t*)smem;                             // [qt][W]  query tile
   uint32_t* st = (uint32_t*)(smem + (size_t)p.qt * W * 8);    // [qt]     block-local copy of tau
   for (uint32_t i = threadIdx.x; i < p.qt * W; i += BLK) sq[i] = p.queries[i];
-  for (uint32_t i = threadIdx.x; i < p.qt; i += BLK) st[i] = vc_ld_relaxed(p.tau + i);
+  for (uint32_t i = threadIdx.x; i < p.qt; i += BLK) st[i] = (VC_SCAN_DIAGNOSTICS && p.wrap) ? 0u : vc_ld_relaxed(p.tau + i);  // wrap: rare path off
   __syncthreads();
 
   constexpr uint64_t CH = 2ull * BLK * U;
-  vc_u64x2 ra[U][W], rb[U][W];
+  vc_u64x2 ra[U][W], rb[NB >= 2 ? U : 1][W], rc[NB >= 3 ? U : 1][W];
 
   auto load = [&](vc_u64x2(&r)[U][W], uint64_t chunk) {
+#if VC_SCAN_DIAGNOSTICS
     if (p.wrap) chunk %= p.wrap;   // diagnostic: keep the stream cache-resident to time the VALU side alone
+#endif
     const uint64_t base = chunk * CH + 2 * threadIdx.x;
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -271,29 +286,28 @@ __global__ void __launch_bounds__(BLK) vc_scan_kernel(const VcScanParams p) {
   // one query against the register-resident code tile: xor + accumulating v_bcnt per 32-bit word, running min
   // over the tile's 2*U items, ONE compare + branch per query.
   auto one_query = [&](const vc_u64x2(&r)[U][W], const uint64_t(&qv)[W], uint32_t t, uint32_t q, uint64_t chunk) {
-    const uint64_t(&qw)[W] = qv;  // VGPR operands: an SGPR source halves the v_xor rate on gfx950 (measured, tools/ubench_bank.hip)
-    // All 2*U items advance in lockstep, one 32-bit word at a time: the 2*U accumulate chains are independent, so
-    // consecutive VALU instructions of a wave never depend on each other (dependency distance 2*U).
-    uint32_t acc[U][2];
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const uint32_t qlo = (uint32_t)qw[j], qhi = (uint32_t)(qw[j] >> 32);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t xa = (uint32_t)r[u][j].x ^ qlo, xb = (uint32_t)r[u][j].y ^ qlo;
-        acc[u][0] = j ? vc_bcnt_acc(xa, acc[u][0]) : vc_bcnt0(xa);
-        acc[u][1] = j ? vc_bcnt_acc(xb, acc[u][1]) : vc_bcnt0(xb);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t xa = (uint32_t)(r[u][j].x >> 32) ^ qhi, xb = (uint32_t)(r[u][j].y >> 32) ^ qhi;
-        acc[u][0] = vc_bcnt_acc(xa, acc[u][0]);
-        acc[u][1] = vc_bcnt_acc(xb, acc[u][1]);
-      }
+#if VC_SCAN_DIAGNOSTICS
+    if (p.diag) {  // diagnostic: a wave "computes" for the same wall time without using the VALU (power/overlap study)
+      for (uint32_t i = 0; i < p.diag; ++i) __builtin_amdgcn_s_sleep(1);
+      return;
     }
+#endif
+    const uint64_t(&qw)[W] = qv;  // VGPR operands: an SGPR source halves the v_xor rate on gfx950 (measured, tools/ubench_bank.hip)
+    // per item pair: W*2 v_xor + W*2 accumulating v_bcnt (two interleaved chains), running min over the tile
     uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll
-    for (int u = 0; u < U; ++u) dmin = min(dmin, min(acc[u][0], acc[u][1]));
+    for (int u = 0; u < U; ++u) {
+      uint32_t da, db;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const uint64_t xa = r[u][j].x ^ qw[j], xb = r[u][j].y ^ qw[j];
+        da = j ? vc_bcnt_acc((uint32_t)xa, da) : vc_bcnt0((uint32_t)xa);
+        db = j ? vc_bcnt_acc((uint32_t)xb, db) : vc_bcnt0((uint32_t)xb);
+        da = vc_bcnt_acc((uint32_t)(xa >> 32), da);
+        db = vc_bcnt_acc((uint32_t)(xb >> 32), db);
+      }
+      dmin = min(dmin, min(da, db));
+    }
     if (__ballot(dmin <= t) != 0) vc_scan_slow<W, U, BLK>(p, r, qw, q, chunk * CH, st);
   };
 
@@ -319,29 +333,42 @@ __global__ void __launch_bounds__(BLK) vc_scan_kernel(const VcScanParams p) {
 
   uint64_t chunk = blockIdx.x;
   if (chunk >= p.nchunks) return;
-  if (!DB) {
+  const uint64_t G = gridDim.x;
+  // chunk to prefetch `ahead` grid strides from `c`; past the end re-read the current chunk (an L2 hit) so the
+  // number of loads in flight is the same on every path and the compiler can wait with a counted vmcnt for the
+  // buffer being verified while the other buffers' loads stay outstanding.
+  auto ahead = [&](uint64_t c, uint64_t k) { return c + k * G < p.nchunks ? c + k * G : c; };
+  if constexpr (NB == 1) {
     // single register buffer: memory latency is covered by the other waves of the SIMD (more of them fit)
-    for (; chunk < p.nchunks; chunk += gridDim.x) {
+    for (; chunk < p.nchunks; chunk += G) {
       load(ra, chunk);
       verify(ra, chunk);
     }
-    return;
-  }
-  load(ra, chunk);
-  // The prefetch is unconditional (past the end it re-reads the block's current chunk, an L2 hit) so the
-  // number of loads in flight is the same on every path and the compiler can wait with a counted vmcnt
-  // for the buffer being verified while the other buffer's loads stay outstanding.
-  for (;;) {
-    uint64_t nx = chunk + gridDim.x;
-    load(rb, nx < p.nchunks ? nx : chunk);
-    verify(ra, chunk);
-    if (nx >= p.nchunks) break;
-    chunk = nx;
-    nx = chunk + gridDim.x;
-    load(ra, nx < p.nchunks ? nx : chunk);
-    verify(rb, chunk);
-    if (nx >= p.nchunks) break;
-    chunk = nx;
+  } else if constexpr (NB == 2) {
+    load(ra, chunk);
+    for (;;) {
+      load(rb, ahead(chunk, 1));
+      verify(ra, chunk);
+      if ((chunk += G) >= p.nchunks) break;
+      load(ra, ahead(chunk, 1));
+      verify(rb, chunk);
+      if ((chunk += G) >= p.nchunks) break;
+    }
+  } else {
+    // three buffers: two chunks in flight behind the one being verified (absorbs HBM latency jitter)
+    load(ra, chunk);
+    load(rb, ahead(chunk, 1));
+    for (;;) {
+      load(rc, ahead(chunk, 2));
+      verify(ra, chunk);
+      if ((chunk += G) >= p.nchunks) break;
+      load(ra, ahead(chunk, 2));
+      verify(rb, chunk);
+      if ((chunk += G) >= p.nchunks) break;
+      load(rb, ahead(chunk, 2));
+      verify(rc, chunk);
+      if ((chunk += G) >= p.nchunks) break;
+    }
   }
 }
 
@@ -359,7 +386,9 @@ struct VcRingSrc {
   const uint32_t* count;
   uint32_t cap;
   const uint32_t* list;   // optional: block b serves ring slot list[b]
+  uint32_t mark_overflow; // report count = UINT32_MAX when the ring overflowed (row is then only an upper bound)
   __device__ uint32_t slot(uint32_t b) const { return list ? list[b] : b; }
+  __device__ bool overflowed(uint32_t q) const { return mark_overflow && count[q] > cap; }
   __device__ uint32_t size(uint32_t q) const { return min(count[q], cap); }
   __device__ uint64_t get(uint32_t q, uint32_t i) const { return buf[(uint64_t)q * cap + i]; }
 };
@@ -367,6 +396,7 @@ struct VcListsSrc {
   const uint64_t* lists;
   uint32_t n_lists, nq, k;
   __device__ uint32_t slot(uint32_t b) const { return b; }
+  __device__ bool overflowed(uint32_t) const { return false; }
   __device__ uint32_t size(uint32_t) const { return n_lists * k; }
   __device__ uint64_t get(uint32_t q, uint32_t i) const {
     return lists[((uint64_t)(i / k) * nq + q) * k + (i % k)];
@@ -490,16 +520,33 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
   if (out_count) {
     atomicAdd(&s_valid, mine);
     __syncthreads();
-    if (threadIdx.x == 0) out_count[q] = s_valid;
+    if (threadIdx.x == 0) out_count[q] = src.overflowed(q) ? 0xFFFFFFFFu : s_valid;
   }
 }
 
+// persistent grid: every block must be resident (a block that waits for a slot would start when the others
+// have almost finished), so grid = CUs x blocks the kernel's registers/LDS admit per CU, capped by the request
+template <class K>
+uint32_t resident_grid(K kernel, int blk, size_t lds, uint32_t n_cu, uint32_t want) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, blk, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  const uint32_t cap = n_cu * (uint32_t)per_cu;
+  return want ? std::min(want, cap) : cap;
+}
+
 template <int W>
-hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t lds, uint32_t grid, hipStream_t s) {
+hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t lds, uint32_t n_cu, uint32_t want, hipStream_t s) {
+#define VC_LAUNCH(NB_, U_, B_)                                                                              \
+  {                                                                                                         \
+    auto kern = vc_scan_kernel<W, U_, B_, NB_>;                                                             \
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nchunks, resident_grid(kern, B_, lds, n_cu, want)); \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(B_), lds, s, p);                                              \
+  }
 #define VC_SCAN_CASE(U_, B_)                                                                     \
   if (sh.unroll == U_ && sh.blk == B_) {                                                         \
-    if (sh.dbuf) hipLaunchKernelGGL((vc_scan_kernel<W, U_, B_, true>), dim3(grid), dim3(B_), lds, s, p);  \
-    else hipLaunchKernelGGL((vc_scan_kernel<W, U_, B_, false>), dim3(grid), dim3(B_), lds, s, p);         \
+    if (sh.dbuf == 3) VC_LAUNCH(3, U_, B_)                                                       \
+    else if (sh.dbuf == 2) VC_LAUNCH(2, U_, B_)                                                  \
+    else VC_LAUNCH(1, U_, B_)                                                                    \
     return hipGetLastError();                                                                    \
   }
   VC_SCAN_CASE(4, 256)
@@ -509,6 +556,7 @@ hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t ld
   VC_SCAN_CASE(2, 512)
   VC_SCAN_CASE(1, 512)
 #undef VC_SCAN_CASE
+#undef VC_LAUNCH
   return hipErrorInvalidValue;
 }
 
@@ -525,13 +573,13 @@ VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes) {
   sh.unroll = W <= 2 ? 4 : (W <= 4 ? 2 : 1);
   // big LDS tiles leave room for one block per CU only: use 512 threads to keep 2 waves per SIMD.
   sh.blk = lds > 40 * 1024 ? 512 : 256;
-  sh.dbuf = 1;
+  sh.dbuf = 2;
   if (const char* e = getenv("VC_SCAN_SHAPE")) {  // dev knob: "U,BLK,DB"
     int u = sh.unroll, b = sh.blk, d = sh.dbuf;
     if (sscanf(e, "%d,%d,%d", &u, &b, &d) >= 1) {
       if ((u == 1 || u == 2 || u == 4) && u * (int)W <= 8) sh.unroll = u;
       if (b == 256 || b == 512) sh.blk = b;
-      sh.dbuf = d != 0;
+      sh.dbuf = d <= 0 ? 1 : (d >= 3 ? 3 : (d == 1 ? 2 : d));   // 0 -> 1 buffer, 1/2 -> 2, 3 -> 3
     }
   }
   return sh;
@@ -595,16 +643,15 @@ hipError_t vc_launch_tau_init(const uint32_t* d_shist, uint32_t hist_stride, uin
   return hipGetLastError();
 }
 
-hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t grid_blocks, hipStream_t s) {
+hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, hipStream_t s) {
   if (p.nchunks == 0 || p.qt == 0) return hipSuccess;
   size_t lds;
   const VcScanShape sh = vc_scan_pick_shape(W, p.qt, &lds);
-  const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nchunks, grid_blocks);
   switch (W) {
-    case 1: return launch_scan_w<1>(p, sh, lds, grid, s);
-    case 2: return launch_scan_w<2>(p, sh, lds, grid, s);
-    case 4: return launch_scan_w<4>(p, sh, lds, grid, s);
-    case 8: return launch_scan_w<8>(p, sh, lds, grid, s);
+    case 1: return launch_scan_w<1>(p, sh, lds, n_cu, want_blocks, s);
+    case 2: return launch_scan_w<2>(p, sh, lds, n_cu, want_blocks, s);
+    case 4: return launch_scan_w<4>(p, sh, lds, n_cu, want_blocks, s);
+    case 8: return launch_scan_w<8>(p, sh, lds, n_cu, want_blocks, s);
   }
   return hipErrorInvalidValue;
 }
@@ -612,7 +659,7 @@ hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t grid_block
 hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, uint32_t nq, uint32_t k,
                                  uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
   if (nq == 0) return hipSuccess;
-  VcRingSrc src{d_buf, d_count, cap, nullptr};
+  VcRingSrc src{d_buf, d_count, cap, nullptr, 1u};
   hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(nq), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
   return hipGetLastError();
 }
@@ -620,7 +667,7 @@ hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint
 hipError_t vc_launch_select_ring_list(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_list,
                                       uint32_t n_list, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
   if (n_list == 0) return hipSuccess;
-  VcRingSrc src{d_buf, d_count, cap, d_list};
+  VcRingSrc src{d_buf, d_count, cap, d_list, 0u};
   hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(n_list), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
   return hipGetLastError();
 }
