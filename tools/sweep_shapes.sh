@@ -1,3 +1,6 @@
-for shape in 4,256,2 4,256,3 2,256,3 2,256,2; do
-  VC_SCAN_SHAPE=$shape timeout -k 10 200 python tools/sweep_scan.py 1e9 128 1,6,8,10,12 0 || exit 1
-done
+VC_BUILD_EXTRA=-DVC_SCAN_NT=0 python -m verticut_amd.build --force > /dev/null 2>&1 || exit 1
+echo "== default-policy loads (no nt)"
+timeout -k 10 200 python tools/sweep_scan.py 1e9 128 1,8,12 0 || exit 1
+python -m verticut_amd.build --force > /dev/null 2>&1 || exit 1
+echo "== nt loads"
+timeout -k 10 200 python tools/sweep_scan.py 1e9 128 1,8,12 0 || exit 1

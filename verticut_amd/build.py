@@ -42,6 +42,7 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         extra = ["-DVC_SCAN_DIAGNOSTICS=1"] if os.environ.get("VC_BUILD_DIAG") == "1" else []
+        extra += os.environ.get("VC_BUILD_EXTRA", "").split()   # dev experiments, e.g. -DVC_SCAN_NT=0
         cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

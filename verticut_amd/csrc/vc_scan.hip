@@ -21,6 +21,15 @@
 #ifndef VC_SCAN_DIAGNOSTICS
 #define VC_SCAN_DIAGNOSTICS 0
 #endif
+// code bytes are read once per launch: non-temporal loads keep them from displacing the query/threshold lines
+#ifndef VC_SCAN_NT
+#define VC_SCAN_NT 1
+#endif
+#if VC_SCAN_NT
+#define VC_SCAN_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define VC_SCAN_LOAD(ptr) (*(ptr))
+#endif
 
 namespace {
 
@@ -279,7 +288,7 @@ __global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : (NB * U * W > 16 ? 3 : 
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < W; ++j)
-        r[u][j] = __builtin_nontemporal_load(
+        r[u][j] = VC_SCAN_LOAD(
             reinterpret_cast<const vc_u64x2*>(p.cols + (uint64_t)j * p.stride + base + (uint64_t)u * 2 * BLK));
   };
 

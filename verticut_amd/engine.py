@@ -68,6 +68,13 @@ def load_library():
         raise ImportError(
             "%s is missing: build it with `python -m verticut_amd.build` (hipcc, gfx950). "
             "verticut_amd has no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so (soname libamdhip64.so.7) and
+    # asks for it as "libamdhip64.so"; if our library pulled in /opt/rocm's copy first, torch would load a second
+    # runtime next to it and find no GPU.  Loading torch first makes our NEEDED libamdhip64.so.7 resolve to that copy.
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
     L.vc_create.argtypes = [C.POINTER(VcConfig), C.POINTER(vp)]
