@@ -118,6 +118,16 @@ int vc_add_codes(vc_engine* e, const void* codes, uint64_t n);
  * (oracle/vc_oracle.cc gen_one) -- used by bench/tests for the BASELINE.json shapes. */
 int vc_add_synthetic(vc_engine* e, uint64_t n, uint64_t seed, uint32_t kind, uint32_t n_centres, uint32_t max_flips);
 int vc_size(const vc_engine* e, uint64_t* n);
+/* The reference's on-disk inputs, honoured as they are:
+ *   code file   headerless records of bits/8 bytes, id = ordinal  (build_hash_tables.cc:40-70, BINARY_CODE_FILE)
+ *   bitmap file raw 2^substr_bits-bit LSB-first uint32 words of one table (generate_bitmap.cc:99-125,
+ *               read back by bitmap_deamon.cc:41-65)
+ * vc_load_code_file appends up to max_records records (0 = all) and reports how many were read;
+ * vc_save_code_file writes the resident records back in id order; vc_write_bitmap_file needs vc_build_index.
+ * The CSR tables themselves are not persisted: rebuilding them from the records takes ~0.5 s per 1e9 codes. */
+int vc_load_code_file(vc_engine* e, const char* path, uint64_t max_records, uint64_t* n_read);
+int vc_save_code_file(vc_engine* e, const char* path);
+int vc_write_bitmap_file(vc_engine* e, uint32_t table, const char* path);
 /* ID -> BinaryCode get (linear_search.cc:45-46; by-id query path image_search_client.h:23-25).
  * id is a global id; out = bits/8 bytes.  VC_NOT_FOUND if id is not in this shard. */
 int vc_get_code(vc_engine* e, uint32_t id, void* out);

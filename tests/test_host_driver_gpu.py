@@ -63,3 +63,58 @@ def test_driver_query_by_id(oracle, tmp_path):
     exp = oracle.linear_knn(codes, codes[1234], k)
     assert sorted(d for _, d in pairs) == [int(x >> SH) for x in exp]
     assert pairs[-1][1] == 0 and (1234, 0) in pairs     # nearest last: the image itself at distance 0
+
+
+def test_accuracy_test_metrics(oracle, tmp_path):
+    """accuracy-test prints the reference's running metrics (accuracy_test.cc:88-91, 106-135)."""
+    n, bits, m, k = 30000, 128, 4, 10
+    rng = np.random.default_rng(33)
+    codes = oracle.gen_codes(n, bits, 11, kind=1, n_centres=60, max_flips=10)
+    q = codes[rng.integers(0, n, size=5)].copy()
+    q[:, 7] ^= 0x09
+    (tmp_path / "lsh.code").write_bytes(codes.tobytes())
+    (tmp_path / "query.code").write_bytes(q.tobytes())
+    exe = os.path.join(ROOT, "verticut_amd", "bin", "accuracy-test")
+    p = subprocess.run([exe, str(tmp_path / "lsh.code"), str(n), str(bits), str(bits // m), str(k), "pilaf", "0", "0", "0",
+                        str(tmp_path / "query.code")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if re.match(r"^[\d.]+ [\d.]+ [\d.e-]+$", l)]
+    assert len(lines) == len(q)
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    tot_ex = tot_app = inacc = 0
+    for i in range(len(q)):
+        ex, _ = mo.find(q[i], k, stop_mult=4)
+        app, _ = mo.find(q[i], k, approximate=True)
+        dex, dapp = [int(v >> SH) for v in ex], sorted((int(v >> SH) for v in app), reverse=True)
+        tot_ex += sum(dex)
+        tot_app += sum(dapp)
+        inacc += next((j for j, d in enumerate(dapp) if d <= dex[0]), len(dapp))   # farthest-first lists
+        a, b, c = (float(x) for x in lines[i].split())
+        assert abs(a - tot_ex / (i + 1) / k) < 1e-3 and abs(b - tot_app / (i + 1) / k) < 1e-3
+        assert abs(c - inacc / (i + 1) / k) < 1e-4
+
+
+def test_code_and_bitmap_file_formats(vc, oracle, tmp_path):
+    """the reference's on-disk inputs: headerless code file in, same bytes out; bitmap file = raw LSB-first words."""
+    n, bits, m = 20000, 64, 4
+    codes = oracle.gen_codes(n, bits, 5, kind=1, n_centres=50, max_flips=4)
+    (tmp_path / "lsh.code").write_bytes(codes.tobytes() + b"\x01\x02\x03")     # trailing partial record is ignored
+    with vc.Engine(bits, capacity=n + 5000, n_tables=m) as e:
+        assert e.load_code_file(tmp_path / "lsh.code", max_records=5000) == 5000
+        assert e.load_code_file(tmp_path / "lsh.code") == n                    # reads from the start again: ids continue
+        assert len(e) == n + 5000 and np.array_equal(e.get_code(5000), codes[0])
+        with pytest.raises(vc.VcError) as ei:                                  # image_total exceeded
+            e.load_code_file(tmp_path / "lsh.code", max_records=1)
+        assert ei.value.code == vc.VC_ERR_CAPACITY
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        assert e.load_code_file(tmp_path / "lsh.code") == n
+        e.save_code_file(tmp_path / "out.code")
+        assert (tmp_path / "out.code").read_bytes() == codes.tobytes()
+        e.build_index()
+        for t in range(m):
+            e.write_bitmap_file(t, tmp_path / ("lsh.code_bmp_%d_2b_4k.raw" % (t + 1)))   # generate_bitmap.cc:84-87 names
+            words = np.frombuffer((tmp_path / ("lsh.code_bmp_%d_2b_4k.raw" % (t + 1))).read_bytes(), dtype=np.uint32)
+            assert words.size == (1 << 16) // 32
+            keys = {int.from_bytes(bytes(c[2 * t:2 * t + 2]), "little") for c in codes}
+            got = {w * 32 + b for w in np.nonzero(words)[0] for b in range(32) if (int(words[w]) >> b) & 1}
+            assert got == keys

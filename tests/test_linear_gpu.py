@@ -97,6 +97,20 @@ def test_many_exact_duplicates(vc, oracle):
         assert np.array_equal(got, exp)
 
 
+def test_second_bootstrap_stage(vc, oracle, monkeypatch):
+    """stage 2 of the threshold bootstrap (normally only for >= 16 M codes) forced on a small database"""
+    monkeypatch.setenv("VC_SAMPLE2", "150000")
+    rng = np.random.default_rng(31)
+    n, bits, k = 200001, 128, 100
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=50, max_flips=12)
+    with vc.Engine(bits, capacity=n) as e:
+        e.add_synthetic(n, seed=34, kind=1, n_centres=50, max_flips=12)
+        q = _queries(oracle, codes, 10, rng)
+        got, cnt = e.search_knn(q, k)
+        exp, ecnt = _expect(oracle, codes, q, k)
+        assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp)
+
+
 def test_ring_overflow_recovery(vc, oracle):
     """more items at the k-th distance than the candidate ring holds: the scan is repeated with the packed bound
     of what did fit until nothing overflows; the answer is still the k smallest (dist, id)."""

@@ -24,7 +24,7 @@ if which == "c2":
         t0 = time.perf_counter(); e.build_index(); tb = time.perf_counter() - t0
         q = near_queries(e, n, nq, bits, radius, rng)
         for mode, name in ((vc.MODE_MIH_EXACT, "mih"), (vc.MODE_LINEAR, "linear")):
-            e.search_radius(q[:64], radius, mode=mode)
+            e.search_radius(q, radius, mode=mode)   # warm: buffers sized for the full batch
             t0 = time.perf_counter(); res = e.search_radius(q, radius, mode=mode); dt = time.perf_counter() - t0
             print(f"c2 n={n} bits={bits} m={m} s={bits//m} radius={radius} {name}: build={tb:.2f}s {nq/dt:9.1f} qps "
                   f"({dt*1e3:.1f} ms / {nq} queries, mean hits {np.mean([len(r) for r in res]):.2f})", flush=True)
@@ -36,7 +36,7 @@ else:
     t0 = time.perf_counter(); e.build_index(); tb = time.perf_counter() - t0
     q = near_queries(e, n, nq, bits, 4, rng)
     for mode, name in ((vc.MODE_MIH_EXACT, "mih_exact"), (vc.MODE_MIH_APPROX, "mih_approx"), (vc.MODE_LINEAR, "linear")):
-        e.search_knn(q[:16], k, mode=mode)
+        e.search_knn(q, k, mode=mode)   # warm: buffers sized for the full batch
         t0 = time.perf_counter(); out, cnt, st = e.search_knn(q, k, mode=mode, with_stats=True); dt = time.perf_counter() - t0
         print(f"knn n={n} clustered bits={bits} m={m} k={k} {name}: build={tb:.2f}s {nq/dt:9.1f} qps ({dt*1e3:.1f} ms / {nq}), "
               f"mean radius {np.mean([s.radius for s in st]):.2f}, mean candidates {np.mean([s.n_candidates for s in st]):.0f}", flush=True)

@@ -25,8 +25,8 @@ def _stale():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    deps += [os.path.join(HERE, "host", f) for f in ("verticut_host.hpp", "distributed_image_search.cc")]
-    if not os.path.exists(os.path.join(HERE, "bin", "distributed-image-search")):
+    deps += [os.path.join(HERE, "host", f) for f in ("verticut_host.hpp", "distributed_image_search.cc", "accuracy_test.cc")]
+    if not all(os.path.exists(os.path.join(HERE, "bin", b)) for b in ("distributed-image-search", "accuracy-test")):
         return True
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -68,10 +68,10 @@ def build_host_tools():
     """C++ host layer above the C ABI (plain g++): the reference-shaped query driver."""
     os.makedirs(BINDIR, exist_ok=True)
     cxx = shutil.which("g++") or "g++"
-    subprocess.check_call([cxx, "-O2", "-std=c++14", "-Wall", "-o", DRIVER,
-                           os.path.join(HOST, "distributed_image_search.cc"), "-I", HOST,
-                           "-L", LIBDIR, "-lverticut_gpu", "-Wl,-rpath,$ORIGIN/../lib",
-                           "-Wl,-rpath-link," + "/opt/rocm/lib", "-L/opt/rocm/lib"])
+    for exe, src in ((DRIVER, "distributed_image_search.cc"), (os.path.join(BINDIR, "accuracy-test"), "accuracy_test.cc")):
+        subprocess.check_call([cxx, "-O2", "-std=c++14", "-Wall", "-o", exe, os.path.join(HOST, src), "-I", HOST,
+                               "-L", LIBDIR, "-lverticut_gpu", "-Wl,-rpath,$ORIGIN/../lib",
+                               "-Wl,-rpath-link," + "/opt/rocm/lib", "-L/opt/rocm/lib"])
     return DRIVER
 
 

@@ -221,6 +221,74 @@ int vc_add_synthetic(vc_engine* e, uint64_t n, uint64_t seed, uint32_t kind, uin
   return VC_OK;
 }
 
+// ---- the reference's file formats ------------------------------------------------------------------
+int vc_load_code_file(vc_engine* e, const char* path, uint64_t max_records, uint64_t* n_read) {
+  if (!e || !path) return VC_ERR_INVALID;
+  FILE* fh = fopen(path, "rb");
+  if (!fh) return fail(e, VC_ERR_INVALID, "Can't open file %s.", path);   // build_hash_tables.cc:30-33
+  const size_t rec = e->bits / 8;
+  const size_t batch = std::max<size_t>(1, (64u << 20) / rec);
+  std::vector<char> buf(batch * rec);
+  uint64_t total = 0;
+  int rc = VC_OK;
+  while (max_records == 0 || total < max_records) {
+    const size_t want = max_records ? (size_t)std::min<uint64_t>(batch, max_records - total) : batch;
+    const size_t got = fread(buf.data(), rec, want, fh);   // a trailing partial record is ignored, as fread(...,1,fh) does
+    if (got == 0) break;
+    if ((rc = vc_add_codes(e, buf.data(), got))) break;
+    total += got;
+  }
+  fclose(fh);
+  if (n_read) *n_read = total;
+  return rc;
+}
+
+int vc_save_code_file(vc_engine* e, const char* path) {
+  if (!e || !path) return VC_ERR_INVALID;
+  int rc = bind_device(e);
+  if (rc) return rc;
+  FILE* fh = fopen(path, "wb");
+  if (!fh) return fail(e, VC_ERR_INVALID, "Can't create file %s.", path);
+  const size_t rec = e->bits / 8;
+  const uint64_t batch = std::max<uint64_t>(1, (64ull << 20) / rec);
+  std::vector<char> buf(batch * rec);
+  std::vector<uint32_t> ids(batch);
+  for (uint64_t off = 0; off < e->n; off += batch) {
+    const uint32_t cnt = (uint32_t)std::min<uint64_t>(batch, e->n - off);
+    if ((rc = grow(e, (uint8_t**)&e->d_stage, &e->stage_bytes, (size_t)cnt * (rec + 4)))) break;
+    uint32_t* d_ids = (uint32_t*)((uint8_t*)e->d_stage + (size_t)cnt * rec);
+    for (uint32_t i = 0; i < cnt; ++i) ids[i] = (uint32_t)(off + i);
+    hipError_t r = hipMemcpyAsync(d_ids, ids.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, e->stream);
+    if (r == hipSuccess) r = vc_launch_gather_rows(e->d_cols, e->stride, e->W, d_ids, cnt, (uint64_t*)e->d_stage, e->stream);
+    if (r == hipSuccess) r = hipMemcpyAsync(buf.data(), e->d_stage, (size_t)cnt * rec, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    if (r != hipSuccess) { rc = fail(e, VC_ERR_HIP, "save: %s", hipGetErrorString(r)); break; }
+    if (fwrite(buf.data(), rec, cnt, fh) != cnt) { rc = fail(e, VC_ERR_INVALID, "short write to %s", path); break; }
+  }
+  fclose(fh);
+  return rc;
+}
+
+int vc_write_bitmap_file(vc_engine* e, uint32_t table, const char* path) {
+  if (!e || !path) return VC_ERR_INVALID;
+  if (!e->mih) return fail(e, VC_ERR_STATE, "no index built");
+  if (table >= e->m) return VC_ERR_INVALID;
+  int rc = bind_device(e);
+  if (rc) return rc;
+  FILE* fh = fopen(path, "wb");
+  if (!fh) return fail(e, VC_ERR_INVALID, "Can't create file %s.", path);
+  const uint64_t words = (1ull << e->sbits) / 32;
+  const uint64_t batch = 16ull << 20;   // 64 MB of words per round
+  std::vector<uint32_t> buf((size_t)std::min(words, batch));
+  for (uint64_t off = 0; off < words && rc == VC_OK; off += batch) {
+    const uint64_t cnt = std::min(batch, words - off);
+    rc = vc_mih_bitmap_read(e->mih, table, off, cnt, buf.data(), e->stream, &e->err);
+    if (rc == VC_OK && fwrite(buf.data(), 4, cnt, fh) != cnt) rc = fail(e, VC_ERR_INVALID, "short write to %s", path);
+  }
+  fclose(fh);
+  return rc;
+}
+
 int vc_get_code(vc_engine* e, uint32_t id, void* out) {
   if (!e || !out) return VC_ERR_INVALID;
   if (id < e->cfg.id_base || (uint64_t)id - e->cfg.id_base >= e->n) return VC_NOT_FOUND;
@@ -303,21 +371,22 @@ int vc_get_timing(const vc_engine* ce, vc_timing* t) {
 struct LinearBufs {
   uint32_t hs, QT, cap;
   size_t state_words;
-  uint32_t *d_count, *d_hist, *d_shist, *d_tau;
+  uint32_t *d_count, *d_hist, *d_shist, *d_shist2, *d_tau;
 };
 
 static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
   b->hs = (e->bits + 1 + 7) & ~7u;
   b->QT = std::min(e->qtile, nq);
   b->cap = std::max(e->cap, 4 * k);
-  b->state_words = (size_t)b->QT * (1 + 2 * (size_t)b->hs + 1);
+  b->state_words = (size_t)b->QT * (1 + 3 * (size_t)b->hs + 1);
   int rc;
   if ((rc = grow(e, &e->d_state, &e->state_bytes, b->state_words * 4))) return rc;
   if ((rc = grow(e, &e->d_ring, &e->ring_bytes, (size_t)b->QT * b->cap * 8))) return rc;
   b->d_count = e->d_state;
   b->d_hist = b->d_count + b->QT;
   b->d_shist = b->d_hist + (size_t)b->QT * b->hs;
-  b->d_tau = b->d_shist + (size_t)b->QT * b->hs;
+  b->d_shist2 = b->d_shist + (size_t)b->QT * b->hs;
+  b->d_tau = b->d_shist2 + (size_t)b->QT * b->hs;
   return VC_OK;
 }
 
@@ -361,13 +430,24 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
   LinearBufs b;
   int rc = linear_bufs(e, nq, k, &b);
   if (rc) return rc;
+  // Threshold bootstrap in two stages.  Stage 1: exact distance histogram of the first `sample` codes -> tau1 (k-th
+  // best of the sample).  Stage 2: histogram of a 32x larger prefix, counting only distances <= tau1 (rare, so it costs
+  // a plain scan of the prefix) -> tau2.  The tighter start keeps the verify kernel's first steps from flooding the
+  // ring / histogram atomics from every wave at once (measured: ~0.4 ms per launch with stage 1 alone).
   const uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(262144, 64ull * k));
+  uint64_t sample2 = std::min<uint64_t>(e->n / 16, sample * 32);
+  if (sample2 < 4 * sample) sample2 = 0;
+  if (const char* s2 = getenv("VC_SAMPLE2")) sample2 = std::min<uint64_t>(e->n, strtoull(s2, nullptr, 10));   // dev/test knob
   for (uint32_t q0 = 0; q0 < nq; q0 += b.QT) {
     const uint32_t qt = std::min(b.QT, nq - q0);
     const uint64_t* dq = d_q + (size_t)q0 * e->W;
     VC_HIP(e, hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
-    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dq, qt, b.d_shist, b.hs, e->n_cu, e->stream));
-    VC_HIP(e, vc_launch_tau_init(b.d_shist, b.hs, qt, k, e->bits, b.d_tau, e->stream));
+    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dq, qt, b.d_shist, b.hs, nullptr, e->n_cu, e->stream));
+    VC_HIP(e, vc_launch_tau_init(b.d_shist, b.hs, qt, k, e->bits, b.d_tau, false, e->stream));
+    if (sample2) {
+      VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample2, dq, qt, b.d_shist2, b.hs, b.d_tau, e->n_cu, e->stream));
+      VC_HIP(e, vc_launch_tau_init(b.d_shist2, b.hs, qt, k, e->bits, b.d_tau, true, e->stream));
+    }
     if ((rc = scan_tile(e, b, dq, qt, k, nullptr))) return rc;
     VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, qt, k, d_out + (size_t)q0 * k, d_cnt + q0, e->stream));
     if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + q0, b.d_count, qt * 4, hipMemcpyDeviceToDevice, e->stream));

@@ -22,6 +22,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 
 #include "vc_internal.hpp"
 #include "vc_mih.hpp"
@@ -407,6 +408,15 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
   if (i < n) p[i] = v;
 }
 
+// sorted ring segments -> one contiguous result array (offs = exclusive prefix of the segment lengths)
+__global__ void __launch_bounds__(256) vc_compact_segments_kernel(const uint64_t* __restrict__ sorted, uint32_t cap,
+                                                                  const uint64_t* __restrict__ offs, uint32_t nq,
+                                                                  uint64_t* __restrict__ out) {
+  const uint32_t q = blockIdx.x;
+  const uint64_t lo = offs[q] - offs[0], n = offs[q + 1] - offs[q];
+  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) out[lo + i] = sorted[(uint64_t)q * cap + i];
+}
+
 __global__ void __launch_bounds__(256) vc_seg_bounds_kernel(const uint32_t* count, uint32_t nq, uint32_t cap, uint32_t* beg,
                                                             uint32_t* end) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -730,7 +740,9 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
     hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, cur, (uint64_t)VC_PACK_INF);
     MIH_CHECK(hipGetLastError());
     uint32_t n_cur = qt;
+    const bool trace = getenv("VC_MIH_TRACE") != nullptr;   // per-shell wall times on stderr
     for (uint32_t r = 0; r <= S && n_cur; ++r) {       // search_worker.cc:170: radius <= n_local_bytes_*8
+      const auto t_shell = std::chrono::steady_clock::now();
       ProbeParams p{};
       p.cols = d_cols; p.stride = stride; p.tables = ix->d_tables; p.queries = d_q + (size_t)q0 * ix->W;
       p.st = st; p.r = r; p.nkeys = binom_host(S, r); p.m = ix->m; p.sbits = S; p.id_base = ix->id_base;
@@ -765,6 +777,9 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
         MIH_CHECK(hipMemsetAsync(d_ctr + 1, 0, 4, s));
         work = cur;
       }
+      if (trace)
+        fprintf(stderr, "[vc_mih] shell r=%u keys=%u active=%u -> next=%u  %.1f us\n", r, p.nkeys, n_cur, h_ctr[0],
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_shell).count());
       n_cur = h_ctr[0];
       std::swap(cur, nxt);
     }
@@ -811,10 +826,12 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
 
   uint64_t* d_ring = nullptr;
   uint64_t* d_sorted = nullptr;
+  uint64_t* d_compact = nullptr;
+  uint64_t compact_cap = 0;
   uint32_t* d_aux = nullptr;     // count[TQ] | tau[TQ] | hist(dummy)[TQ*8] | beg[TQ] | end[TQ]
   void* d_temp = nullptr;
   size_t temp_bytes = 0;
-  auto cleanup = [&]() { (void)hipFree(d_ring); (void)hipFree(d_sorted); (void)hipFree(d_aux); (void)hipFree(d_temp); };
+  auto cleanup = [&]() { (void)hipFree(d_ring); (void)hipFree(d_sorted); (void)hipFree(d_compact); (void)hipFree(d_aux); (void)hipFree(d_temp); };
 #define R_CHECK(call)                                                      \
   do {                                                                     \
     hipError_t _r = (call);                                                \
@@ -897,13 +914,24 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
     R_CHECK(hipGetLastError());
     R_CHECK(hipcub::DeviceSegmentedRadixSort::SortKeys(d_temp, temp_bytes, d_ring, d_sorted, (int64_t)qt * cap, (int)qt, d_beg, d_end,
                                                        0, 44, s));
-    for (uint32_t i = 0; i < qt; ++i) {
+    for (uint32_t i = 0; i < qt; ++i) offs[q0 + i + 1] = offs[q0 + i] + h_count[i];
+    const uint64_t tile_total = offs[q0 + qt] - offs[q0];
+    if (tile_total) {   // gather the tile's segments on the device, one copy back
+      if (tile_total > compact_cap) {
+        (void)hipFree(d_compact);
+        d_compact = nullptr;
+        compact_cap = tile_total * 2;
+        R_CHECK(hipMalloc((void**)&d_compact, compact_cap * 8 + (TQ + 1) * 8));
+      }
+      uint64_t* d_offs = d_compact + compact_cap;
+      R_CHECK(hipMemcpyAsync(d_offs, offs.data() + q0, (size_t)(qt + 1) * 8, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(vc_compact_segments_kernel, dim3(qt), dim3(256), 0, s, d_sorted, cap, d_offs, qt, d_compact);
+      R_CHECK(hipGetLastError());
       const size_t base = result.size();
-      result.resize(base + h_count[i]);
-      if (h_count[i]) R_CHECK(hipMemcpyAsync(result.data() + base, d_sorted + (size_t)i * cap, (size_t)h_count[i] * 8, hipMemcpyDeviceToHost, s));
-      offs[q0 + i + 1] = offs[q0 + i] + h_count[i];
+      result.resize(base + tile_total);
+      R_CHECK(hipMemcpyAsync(result.data() + base, d_compact, tile_total * 8, hipMemcpyDeviceToHost, s));
+      R_CHECK(hipStreamSynchronize(s));
     }
-    R_CHECK(hipStreamSynchronize(s));
   }
 #undef R_CHECK
   cleanup();

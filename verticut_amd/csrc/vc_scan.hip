@@ -123,14 +123,17 @@ __device__ __forceinline__ uint32_t vc_dist(const uint64_t (&c)[W], const uint64
 template <int W>
 __global__ void __launch_bounds__(256) vc_sample_hist_kernel(const uint64_t* __restrict__ cols, uint64_t stride,
                                                              uint64_t s_items, const uint64_t* __restrict__ queries,
-                                                             uint32_t qt, uint32_t* __restrict__ shist, uint32_t hs) {
+                                                             uint32_t qt, uint32_t* __restrict__ shist, uint32_t hs,
+                                                             const uint32_t* __restrict__ thr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t q0 = blockIdx.y * VC_SAMPLE_QSUB;
   const uint32_t nq = min((uint32_t)VC_SAMPLE_QSUB, qt - q0);
   uint64_t* sq = (uint64_t*)smem;                                      // [nq][W]
   uint32_t* lh = (uint32_t*)(smem + (size_t)VC_SAMPLE_QSUB * W * 8);   // [nq][hs]
+  uint32_t* sthr = lh + (size_t)VC_SAMPLE_QSUB * hs;                   // [nq] only distances <= thr are counted
   for (uint32_t i = threadIdx.x; i < nq * W; i += blockDim.x) sq[i] = queries[(uint64_t)q0 * W + i];
   for (uint32_t i = threadIdx.x; i < nq * hs; i += blockDim.x) lh[i] = 0;
+  for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) sthr[i] = thr ? thr[q0 + i] : 0xFFFFFFFFu;
   __syncthreads();
 
   const uint64_t npairs = (s_items + 1) / 2;
@@ -147,8 +150,10 @@ __global__ void __launch_bounds__(256) vc_sample_hist_kernel(const uint64_t* __r
       uint64_t qw[W];
 #pragma unroll
       for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
-      atomicAdd(&lh[q * hs + vc_dist<W>(a, qw)], 1u);
-      if (vb) atomicAdd(&lh[q * hs + vc_dist<W>(b, qw)], 1u);
+      const uint32_t t = sthr[q];
+      const uint32_t da = vc_dist<W>(a, qw), db = vc_dist<W>(b, qw);
+      if (da <= t) atomicAdd(&lh[q * hs + da], 1u);
+      if (vb && db <= t) atomicAdd(&lh[q * hs + db], 1u);
     }
   }
   __syncthreads();
@@ -182,10 +187,11 @@ __device__ __forceinline__ uint32_t vc_hist_cut(const uint32_t* h, uint32_t nbin
 }
 
 __global__ void __launch_bounds__(64) vc_tau_init_kernel(const uint32_t* __restrict__ shist, uint32_t hs, uint32_t k,
-                                                         uint32_t bits, uint32_t* __restrict__ tau) {
+                                                         uint32_t bits, uint32_t* __restrict__ tau, uint32_t refine) {
   const uint32_t q = blockIdx.x;
   const uint32_t cut = vc_hist_cut(shist + (uint64_t)q * hs, bits + 1, k, false);
-  if (threadIdx.x == 0) tau[q] = (cut == 0xFFFFFFFFu) ? bits : cut;
+  // first stage: no cut (fewer than k samples) means "accept everything"; refining stage: keep the previous bound
+  if (threadIdx.x == 0) tau[q] = (cut == 0xFFFFFFFFu) ? (refine ? tau[q] : bits) : (refine ? min(cut, tau[q]) : cut);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -622,16 +628,16 @@ hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t
 
 hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
-                                 uint32_t n_cu, hipStream_t s) {
+                                 const uint32_t* d_thr, uint32_t n_cu, hipStream_t s) {
   if (s_items == 0 || qt == 0) return hipSuccess;
   const uint32_t gy = (qt + VC_SAMPLE_QSUB - 1) / VC_SAMPLE_QSUB;
   const uint64_t npairs = (s_items + 1) / 2;
-  const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * 4);
-  const size_t lds = (size_t)VC_SAMPLE_QSUB * W * 8 + (size_t)VC_SAMPLE_QSUB * hist_stride * 4;
+  const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * 8);
+  const size_t lds = (size_t)VC_SAMPLE_QSUB * W * 8 + (size_t)VC_SAMPLE_QSUB * hist_stride * 4 + VC_SAMPLE_QSUB * 4;
 #define VC_SH_CASE(W_)                                                                                         \
   case W_:                                                                                                     \
     hipLaunchKernelGGL((vc_sample_hist_kernel<W_>), dim3(gx, gy), dim3(256), lds, s, cols, stride, s_items,     \
-                       d_queries, qt, d_shist, hist_stride);                                                   \
+                       d_queries, qt, d_shist, hist_stride, d_thr);                                            \
     break;
   switch (W) {
     VC_SH_CASE(1)
@@ -646,9 +652,9 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
 }
 
 hipError_t vc_launch_tau_init(const uint32_t* d_shist, uint32_t hist_stride, uint32_t qt, uint32_t k, uint32_t bits,
-                              uint32_t* d_tau, hipStream_t s) {
+                              uint32_t* d_tau, bool refine, hipStream_t s) {
   if (qt == 0) return hipSuccess;
-  hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau);
+  hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u);
   return hipGetLastError();
 }
 

@@ -25,6 +25,7 @@ EXPORTS = [
     "vc_create", "vc_destroy", "vc_last_error", "vc_strerror", "vc_abi_version", "vc_add_codes", "vc_add_synthetic",
     "vc_size", "vc_get_code", "vc_build_index", "vc_get_bucket", "vc_bitmap_test", "vc_bitmap_read", "vc_search_knn",
     "vc_search_knn_dev", "vc_search_radius", "vc_merge_topk_dev", "vc_get_timing", "vc_set_stream",
+    "vc_load_code_file", "vc_save_code_file", "vc_write_bitmap_file",
 ]
 
 
@@ -95,6 +96,9 @@ def load_library():
     L.vc_search_knn_dev.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp]
     L.vc_search_radius.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp]
     L.vc_merge_topk_dev.argtypes = [vp, u32, u32, u32, vp, vp, vp]
+    L.vc_load_code_file.argtypes = [vp, C.c_char_p, u64, C.POINTER(u64)]
+    L.vc_save_code_file.argtypes = [vp, C.c_char_p]
+    L.vc_write_bitmap_file.argtypes = [vp, u32, C.c_char_p]
     L.vc_get_timing.argtypes = [vp, C.POINTER(VcTiming)]
     L.vc_set_stream.argtypes = [vp, vp]
     for name in EXPORTS:
@@ -169,6 +173,19 @@ class Engine:
 
     def add_synthetic(self, n, seed, kind=SYNTH_UNIFORM, n_centres=0, max_flips=0):
         self._check(self._L.vc_add_synthetic(self._h, n, seed, kind, n_centres, max_flips))
+
+    def load_code_file(self, path, max_records=0):
+        """headerless records of bits/8 bytes (the reference's BINARY_CODE_FILE); returns records appended"""
+        n = C.c_uint64()
+        self._check(self._L.vc_load_code_file(self._h, os.fsencode(path), max_records, C.byref(n)))
+        return n.value
+
+    def save_code_file(self, path):
+        self._check(self._L.vc_save_code_file(self._h, os.fsencode(path)))
+
+    def write_bitmap_file(self, table, path):
+        """raw LSB-first uint32 words of one table's occupancy bitmap (generate_bitmap.cc:122-125 format)"""
+        self._check(self._L.vc_write_bitmap_file(self._h, table, os.fsencode(path)))
 
     def __len__(self):
         n = C.c_uint64()
