@@ -105,7 +105,7 @@ def main():
 
     n_total = int(args.n)
     Q, k = args.queries, args.k
-    ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=local_rank, query_tile=Q)
+    ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=local_rank, query_tile=Q, pipelined=True)
     ss.add_synthetic(args.seed)
 
     # query batches resident in HBM: uniform random codes = worst case (no early threshold help)
@@ -126,6 +126,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out, cnt = ss.search(dev_q[i % nb], k)
+    ss.flush()                      # N > 1: exchanges of the last batches (side stream) join the main stream
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     if world > 1:

@@ -39,6 +39,21 @@ def _worker(rank, world, port, total_n, bits, k, ret):
     torch.cuda.synchronize()
     got2 = out2.cpu().numpy().view(np.uint64)
     ok = ok and bool(np.array_equal(got2 >> np.uint64(32), exp >> np.uint64(32)))
+    # pipelined exchange (side stream, two buffer sets): five batches in flight, every result still exact
+    sp = ShardedSearch(bits, total_n, rank=rank, world=world, device=0, pipelined=True, backend=ss.backend)
+    outs = []
+    for r in range(5):
+        qq = np.roll(q, r, axis=0).copy()
+        o, _ = sp.search(torch.from_numpy(qq).cuda(), k)
+        outs.append((r, o))                  # a buffer set is reused two batches later, by design
+        if r < 3:
+            sp.flush()
+            torch.cuda.synchronize()
+            ok = ok and bool(np.array_equal(o.cpu().numpy().view(np.uint64), np.roll(exp, r, axis=0)))
+    sp.flush()
+    torch.cuda.synchronize()
+    for r in (3, 4):                         # the last two batches sit in the two buffer sets
+        ok = ok and bool(np.array_equal(outs[r][1].cpu().numpy().view(np.uint64), np.roll(exp, r, axis=0)))
     ret[rank] = ok
     ss.close()
     dist.destroy_process_group()

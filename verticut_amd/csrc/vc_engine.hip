@@ -434,10 +434,11 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
   // best of the sample).  Stage 2: histogram of a 32x larger prefix, counting only distances <= tau1 (rare, so it costs
   // a plain scan of the prefix) -> tau2.  The tighter start keeps the verify kernel's first steps from flooding the
   // ring / histogram atomics from every wave at once (measured: ~0.4 ms per launch with stage 1 alone).
-  const uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(262144, 64ull * k));
-  uint64_t sample2 = std::min<uint64_t>(e->n / 16, sample * 32);
+  uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(262144, 64ull * k));
+  uint64_t sample2 = std::min<uint64_t>(e->n / 16, sample * 32);   // 8.4 M codes at k = 100 (measured optimum 8-16 M)
   if (sample2 < 4 * sample) sample2 = 0;
   if (const char* s2 = getenv("VC_SAMPLE2")) sample2 = std::min<uint64_t>(e->n, strtoull(s2, nullptr, 10));   // dev/test knob
+  if (sample2) sample = std::min<uint64_t>(sample, std::max<uint64_t>(65536, 64ull * k));   // stage 1 only has to seed stage 2
   for (uint32_t q0 = 0; q0 < nq; q0 += b.QT) {
     const uint32_t qt = std::min(b.QT, nq - q0);
     const uint64_t* dq = d_q + (size_t)q0 * e->W;
@@ -449,7 +450,7 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
       VC_HIP(e, vc_launch_tau_init(b.d_shist2, b.hs, qt, k, e->bits, b.d_tau, true, e->stream));
     }
     if ((rc = scan_tile(e, b, dq, qt, k, nullptr))) return rc;
-    VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, qt, k, d_out + (size_t)q0 * k, d_cnt + q0, e->stream));
+    VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, qt, k, d_out + (size_t)q0 * k, d_cnt + q0, e->stream));
     if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + q0, b.d_count, qt * 4, hipMemcpyDeviceToDevice, e->stream));
   }
   return VC_OK;
@@ -490,7 +491,7 @@ static int linear_recover(vc_engine* e, const uint64_t* d_q, uint32_t k, const s
       RC(hipMemcpyAsync(d_lim, lim.data(), qt * 8, hipMemcpyHostToDevice, e->stream));
       RC(hipMemcpyAsync(b.d_tau, tau.data(), qt * 4, hipMemcpyHostToDevice, e->stream));
       if ((rc = scan_tile(e, b, d_rq, qt, k, d_lim))) { cleanup(); return rc; }
-      RC(vc_launch_select_ring(e->d_ring, b.cap, b.d_count, qt, k, d_rout, d_rcnt, e->stream));
+      RC(vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, qt, k, d_rout, d_rcnt, e->stream));
       std::vector<uint64_t> rout((size_t)qt * k);
       std::vector<uint32_t> rcnt(qt), raw(qt);
       RC(hipMemcpyAsync(rout.data(), d_rout, rout.size() * 8, hipMemcpyDeviceToHost, e->stream));

@@ -402,7 +402,9 @@ struct VcRingSrc {
   uint32_t cap;
   const uint32_t* list;   // optional: block b serves ring slot list[b]
   uint32_t mark_overflow; // report count = UINT32_MAX when the ring overflowed (row is then only an upper bound)
+  const uint32_t* tau;    // optional final distance thresholds: entries farther than tau[q] cannot be in the top-k
   __device__ uint32_t slot(uint32_t b) const { return list ? list[b] : b; }
+  __device__ uint64_t bound(uint32_t q) const { return tau ? (((uint64_t)tau[q] + 1) << 32) : VC_PACK_INF; }
   __device__ bool overflowed(uint32_t q) const { return mark_overflow && count[q] > cap; }
   __device__ uint32_t size(uint32_t q) const { return min(count[q], cap); }
   __device__ uint64_t get(uint32_t q, uint32_t i) const { return buf[(uint64_t)q * cap + i]; }
@@ -411,6 +413,7 @@ struct VcListsSrc {
   const uint64_t* lists;
   uint32_t n_lists, nq, k;
   __device__ uint32_t slot(uint32_t b) const { return b; }
+  __device__ uint64_t bound(uint32_t) const { return VC_PACK_INF; }
   __device__ bool overflowed(uint32_t) const { return false; }
   __device__ uint32_t size(uint32_t) const { return n_lists * k; }
   __device__ uint64_t get(uint32_t q, uint32_t i) const {
@@ -450,10 +453,19 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
   uint32_t P;
 
   if (n <= VC_SORT_CAP) {
-    P = 1;
-    while (P < n) P <<= 1;
-    if (P < 2) P = 2;
-    for (uint32_t i = threadIdx.x; i < P; i += VC_SEL_THREADS) a[i] = i < n ? src.get(q, i) : VC_PACK_INF;
+    // compact the entries that can still matter (below the final threshold when the source has one), then sort those
+    const uint64_t bound = src.bound(q);
+    if (threadIdx.x == 0) s_fill = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += VC_SEL_THREADS) {
+      const uint64_t v = src.get(q, i);
+      if (v < bound) a[atomicAdd(&s_fill, 1u)] = v;
+    }
+    __syncthreads();
+    const uint32_t fill = s_fill;
+    P = 2;
+    while (P < fill) P <<= 1;
+    for (uint32_t i = fill + threadIdx.x; i < P; i += VC_SEL_THREADS) a[i] = VC_PACK_INF;
   } else {
     // ---- radix select on the 44 low bits (dist < 2048, id 32 bit); padding (INF) never participates
     if (threadIdx.x == 0) s_valid = 0;
@@ -671,10 +683,10 @@ hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint
   return hipErrorInvalidValue;
 }
 
-hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, uint32_t nq, uint32_t k,
-                                 uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
+hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_tau,
+                                 uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
   if (nq == 0) return hipSuccess;
-  VcRingSrc src{d_buf, d_count, cap, nullptr, 1u};
+  VcRingSrc src{d_buf, d_count, cap, nullptr, 1u, d_tau};
   hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(nq), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
   return hipGetLastError();
 }
@@ -682,7 +694,7 @@ hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint
 hipError_t vc_launch_select_ring_list(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_list,
                                       uint32_t n_list, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
   if (n_list == 0) return hipSuccess;
-  VcRingSrc src{d_buf, d_count, cap, d_list, 0u};
+  VcRingSrc src{d_buf, d_count, cap, d_list, 0u, nullptr};
   hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(n_list), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
   return hipGetLastError();
 }

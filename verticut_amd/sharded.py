@@ -59,8 +59,15 @@ class ShardedSearch:
     """
 
     def __init__(self, bits, total_n, rank=None, world=None, n_tables=0, device=None, group=None, backend=None,
-                 **engine_kw):
+                 pipelined=False, **engine_kw):
+        """pipelined=True: the all-gather + merge of batch i run on a side stream while batch i+1 is already being
+        scanned; results of a call are then ordered on the caller's stream only after flush() (or two calls later)."""
         self.group = group
+        self.pipelined = pipelined
+        self._side = None
+        self._sets = [None, None]
+        self._done = [None, None]
+        self._step = 0
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
         self.bits, self.nbytes, self.total_n = bits, bits // 8, total_n
@@ -97,7 +104,46 @@ class ShardedSearch:
             self._buf_key = key
         return self._local, self._lcnt, self._gath, self._out, self._ocnt
 
+    def _search_pipelined(self, queries, k, mode):
+        nq = queries.shape[0]
+        j = self._step & 1
+        self._step += 1
+        key = (nq, k, str(queries.device))
+        if self._sets[j] is None or self._sets[j][0] != key:
+            dev = queries.device
+            self._sets[j] = (key, torch.empty((nq, k), dtype=torch.int64, device=dev),
+                             torch.empty((nq,), dtype=torch.int32, device=dev),
+                             torch.empty((self.world, nq, k), dtype=torch.int64, device=dev),
+                             torch.empty((nq, k), dtype=torch.int64, device=dev),
+                             torch.empty((nq,), dtype=torch.int32, device=dev))
+        _, local, lcnt, gath, out, ocnt = self._sets[j]
+        main = torch.cuda.current_stream(queries.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=queries.device)
+        if self._done[j] is not None:        # buffer set j was last used two batches ago: its exchange must be over
+            main.wait_event(self._done[j])
+        self.backend.local_topk(queries, k, local, lcnt, mode)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            work = dist.all_gather_into_tensor(gath.view(self.world * nq, k), local, group=self.group, async_op=True)
+            work.wait()                      # orders the side stream after the collective
+            self.backend.merge(gath, self.world, nq, k, out, ocnt)
+            done = torch.cuda.Event()
+            done.record(self._side)
+            self._done[j] = done
+        return out, ocnt
+
+    def flush(self):
+        """make the caller's current stream wait for every exchange still in flight (pipelined mode)"""
+        for ev in self._done:
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
     def search(self, queries, k, mode=vc.MODE_LINEAR):
+        if self.pipelined and self.world > 1 and queries.is_cuda:
+            return self._search_pipelined(queries, k, mode)
         nq = queries.shape[0]
         local, lcnt, gath, out, ocnt = self._buffers(nq, k, queries.device)
         self.backend.local_topk(queries, k, local, lcnt, mode)
