@@ -78,7 +78,7 @@ typedef struct vc_config {
   int32_t device;        /* HIP device ordinal, -1 = current */
   uint32_t cand_cap;     /* per-query candidate ring entries, 0 = default (65536) */
   uint32_t scan_blocks;  /* 0 = default grid for the verify kernel (tuning knob) */
-  uint32_t query_tile;   /* 0 = default number of queries verified per DB pass (tuning knob) */
+  uint32_t query_tile;   /* queries verified per DB pass; 0 = default (32).  8 = HBM-bound pass, see DESIGN.md 4.1 */
   uint32_t reserved[5];
 } vc_config;
 

@@ -1,0 +1,141 @@
+"""Edge cases of the C ABI on the GPU: empty / tiny databases, extreme k, many query tiles, argument errors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+INF = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def test_empty_database(vc):
+    q = np.zeros((3, 16), dtype=np.uint8)
+    with vc.Engine(128, capacity=100, n_tables=4) as e:
+        out, cnt = e.search_knn(q, 10)
+        assert np.all(cnt == 0) and np.all(out == INF)
+        e.build_index()
+        out, cnt, st = e.search_knn(q, 10, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        assert np.all(cnt == 0) and all(s.radius == 32 for s in st)     # loop runs to the last shell (search_worker.cc:170)
+        assert all(len(r) == 0 for r in e.search_radius(q, 5))
+        assert all(len(r) == 0 for r in e.search_radius(q, 5, mode=vc.MODE_MIH_EXACT))
+        assert e.get_code(0) is None and e.get_bucket(0, 0) is None
+
+
+def test_single_item_and_k1(vc, oracle):
+    code = np.arange(16, dtype=np.uint8)[None, :]
+    with vc.Engine(128, capacity=1, n_tables=4, id_base=77) as e:
+        e.add_codes(code)
+        e.build_index()
+        q = code.copy()
+        q[0, 0] ^= 0x7
+        for mode in (vc.MODE_LINEAR, vc.MODE_MIH_EXACT, vc.MODE_MIH_APPROX):
+            out, cnt = e.search_knn(q, 1, mode=mode)
+            assert cnt[0] == 1 and int(out[0, 0]) == (3 << 32 | 77)
+
+
+def test_max_k_and_k_larger_than_db(vc, oracle):
+    n, bits = 20000, 64
+    codes = oracle.gen_codes(n, bits, 3)
+    q = codes[:2].copy()
+    with vc.Engine(bits, capacity=n) as e:
+        e.add_synthetic(n, seed=3)
+        out, cnt = e.search_knn(q, 8192)                       # VC_MAX_K
+        exp = oracle.linear_knn(codes, q[0], 8192)
+        assert cnt[0] == 8192 and np.array_equal(out[0], exp)
+        with pytest.raises(vc.VcError) as ei:
+            e.search_knn(q, 8193)
+        assert ei.value.code == vc.VC_ERR_INVALID
+    with vc.Engine(bits, capacity=5000) as e:
+        e.add_codes(codes[:5000])
+        out, cnt = e.search_knn(q, 8192)                       # k > N: everything, ascending, INF padded
+        exp = oracle.linear_knn(codes[:5000], q[1], 8192)
+        assert cnt[1] == 5000 and np.array_equal(out[1, :5000], exp) and np.all(out[1, 5000:] == INF)
+
+
+def test_many_query_tiles(vc, oracle):
+    n, bits, k, nq = 30000, 128, 7, 203                        # 203 queries = 6 full tiles of 32 + 11
+    rng = np.random.default_rng(1)
+    codes = oracle.gen_codes(n, bits, 9, kind=1, n_centres=40, max_flips=9)
+    q = codes[rng.integers(0, n, size=nq)].copy()
+    q[:, 4] ^= 0x21
+    with vc.Engine(bits, capacity=n, n_tables=4) as e:
+        e.add_synthetic(n, seed=9, kind=1, n_centres=40, max_flips=9)
+        out, cnt = e.search_knn(q, k)
+        for i in range(nq):
+            assert np.array_equal(out[i], oracle.linear_knn(codes, q[i], k)), i
+        e.build_index()
+        mout, mcnt = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT)   # > one MIH tile? (256) no; but all queries at once
+        assert np.array_equal(mout >> np.uint64(32), out >> np.uint64(32))
+
+
+def test_more_queries_than_one_mih_tile(vc, oracle):
+    n, bits, k, nq = 20000, 64, 5, 300                          # MIH tiles hold 256 queries
+    rng = np.random.default_rng(2)
+    codes = oracle.gen_codes(n, bits, 4, kind=1, n_centres=30, max_flips=4)
+    q = codes[rng.integers(0, n, size=nq)].copy()
+    with vc.Engine(bits, capacity=n, n_tables=4) as e:
+        e.add_codes(codes)
+        e.build_index()
+        lin, _ = e.search_knn(q, k)
+        mih, _, st = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        assert np.array_equal(mih >> np.uint64(32), lin >> np.uint64(32))
+        assert all(s.n_results == k for s in st)
+        res = e.search_radius(q, 6, mode=vc.MODE_MIH_EXACT)
+        ref = e.search_radius(q, 6, mode=vc.MODE_LINEAR)
+        assert all(np.array_equal(a, b) for a, b in zip(res, ref))
+
+
+def test_argument_errors(vc):
+    L = vc.load_library()
+
+    def create(**kw):
+        cfg = vc.VcConfig(abi_version=vc.VC_ABI_VERSION, bits=128, n_tables=4, capacity=10, device=-1)
+        for k_, v in kw.items():
+            setattr(cfg, k_, v)
+        h = C.c_void_p()
+        rc = L.vc_create(C.byref(cfg), C.byref(h))
+        if rc == 0:
+            L.vc_destroy(h)
+        return rc
+
+    assert create() == vc.VC_OK
+    assert create(abi_version=99) == vc.VC_ERR_INVALID
+    assert create(bits=100) == vc.VC_ERR_INVALID
+    assert create(n_tables=3) == vc.VC_ERR_INVALID            # 16 bytes not divisible (search_worker.cc:75 assert)
+    assert create(bits=256, n_tables=4) == vc.VC_ERR_INVALID  # 64-bit substrings: binaryToInt stops at 32
+    assert create(capacity=0) == vc.VC_ERR_INVALID
+    assert create(capacity=1 << 32, id_base=1) == vc.VC_ERR_INVALID   # ids are uint32
+    assert create(device=99) == vc.VC_ERR_NO_DEVICE
+    with vc.Engine(128, capacity=10) as e:                   # linear-only engine
+        with pytest.raises(vc.VcError) as ei:
+            e.build_index()
+        assert ei.value.code == vc.VC_ERR_STATE
+        with pytest.raises(vc.VcError):
+            e.get_bucket(0, 0)
+        with pytest.raises(vc.VcError) as ei:
+            e.add_synthetic(11, seed=1)
+        assert ei.value.code == vc.VC_ERR_CAPACITY
+        with pytest.raises(vc.VcError):
+            e.search_knn(np.zeros((1, 16), np.uint8), 0)
+        with pytest.raises(ValueError):
+            e.search_knn(np.zeros((1, 8), np.uint8), 1)
+
+
+def test_device_api_matches_host_api(vc, oracle):
+    import torch
+    n, bits, k = 50000, 128, 20
+    codes = oracle.gen_codes(n, bits, 6)
+    q = codes[:9].copy()
+    q[:, 9] ^= 0x55
+    with vc.Engine(bits, capacity=n) as e:
+        e.add_synthetic(n, seed=6)
+        host, hcnt = e.search_knn(q, k)
+        dq = torch.from_numpy(q).cuda()
+        out = torch.empty((9, k), dtype=torch.int64, device="cuda")
+        cnt = torch.empty((9,), dtype=torch.int32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        e.search_knn_dev(dq.data_ptr(), 9, k, out.data_ptr(), cnt.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), host) and np.array_equal(cnt.cpu().numpy(), hcnt)
+        t = e.timing()
+        assert t.calls == 2 and t.scan_launches == 2

@@ -17,7 +17,7 @@ struct vc_engine {
   vc_config cfg;
   int device = 0;
   uint32_t bits = 0, W = 0, m = 0, sbits = 0, n_cu = 0;
-  uint32_t cap = 65536, qtile = 16, scan_blocks = 0;
+  uint32_t cap = 65536, qtile = 32, scan_blocks = 0;
   uint64_t n = 0, stride = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   uint64_t* d_cols = nullptr;
@@ -133,7 +133,9 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
   e->sbits = sbits;
   e->n_cu = (uint32_t)prop.multiProcessorCount;
   e->cap = cfg->cand_cap ? cfg->cand_cap : 65536u;
-  e->qtile = cfg->query_tile ? cfg->query_tile : 16u;
+  // queries verified per database pass: 8 keeps the pass on the HBM side of the roofline (bench), larger tiles trade
+  // bandwidth efficiency for queries/s until the popcount VALU ceiling; default for big batches: 32
+  e->qtile = cfg->query_tile ? cfg->query_tile : 32u;
   if (const char* s = getenv("VC_QUERY_TILE")) e->qtile = (uint32_t)std::max(1, atoi(s));
   e->scan_blocks = cfg->scan_blocks;
   if (const char* s = getenv("VC_SCAN_BLOCKS")) e->scan_blocks = (uint32_t)std::max(1, atoi(s));
@@ -443,12 +445,11 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
     const uint32_t qt = std::min(b.QT, nq - q0);
     const uint64_t* dq = d_q + (size_t)q0 * e->W;
     VC_HIP(e, hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
-    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dq, qt, b.d_shist, b.hs, nullptr, e->n_cu, e->stream));
-    VC_HIP(e, vc_launch_tau_init(b.d_shist, b.hs, qt, k, e->bits, b.d_tau, false, e->stream));
-    if (sample2) {
-      VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample2, dq, qt, b.d_shist2, b.hs, b.d_tau, e->n_cu, e->stream));
-      VC_HIP(e, vc_launch_tau_init(b.d_shist2, b.hs, qt, k, e->bits, b.d_tau, true, e->stream));
-    }
+    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dq, qt, b.d_shist, b.hs, k, e->bits, b.d_tau, false,
+                                    e->n_cu, e->stream));
+    if (sample2)
+      VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample2, dq, qt, b.d_shist2, b.hs, k, e->bits, b.d_tau, true,
+                                      e->n_cu, e->stream));
     if ((rc = scan_tile(e, b, dq, qt, k, nullptr))) return rc;
     VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, qt, k, d_out + (size_t)q0 * k, d_cnt + q0, e->stream));
     if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + q0, b.d_count, qt * 4, hipMemcpyDeviceToDevice, e->stream));

@@ -19,11 +19,11 @@ hipError_t vc_launch_rows_to_cols(const uint64_t* rows, uint64_t* cols, uint64_t
                                   uint64_t first_local, uint64_t n, hipStream_t s);
 hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t W, const uint32_t* d_local_ids,
                                  uint32_t n_ids, uint64_t* d_rows, hipStream_t s);
+// One stage of the threshold bootstrap (two launches): histogram of the first s_items codes (refine: only
+// distances <= tau[q]), then tau[q] = k-th smallest sampled distance.  d_shist [qt][hist_stride] must be zero.
 hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
-                                 const uint32_t* d_thr /*nullable: count only distances <= thr[q]*/, uint32_t n_cu, hipStream_t s);
-hipError_t vc_launch_tau_init(const uint32_t* d_shist, uint32_t hist_stride, uint32_t qt, uint32_t k, uint32_t bits,
-                              uint32_t* d_tau, bool refine, hipStream_t s);
+                                 uint32_t k, uint32_t bits, uint32_t* d_tau, bool refine, uint32_t n_cu, hipStream_t s);
 // grid = min(chunks, CUs x resident blocks per CU, want_blocks if non-zero)
 hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, hipStream_t s);
 // ring -> sorted top-k (per query); out padded with VC_PACK_INF

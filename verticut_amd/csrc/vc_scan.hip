@@ -120,51 +120,7 @@ __device__ __forceinline__ uint32_t vc_dist(const uint64_t (&c)[W], const uint64
 // ------------------------------------------------------------------------------------------
 #define VC_SAMPLE_QSUB 32
 
-template <int W>
-__global__ void __launch_bounds__(256) vc_sample_hist_kernel(const uint64_t* __restrict__ cols, uint64_t stride,
-                                                             uint64_t s_items, const uint64_t* __restrict__ queries,
-                                                             uint32_t qt, uint32_t* __restrict__ shist, uint32_t hs,
-                                                             const uint32_t* __restrict__ thr) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t q0 = blockIdx.y * VC_SAMPLE_QSUB;
-  const uint32_t nq = min((uint32_t)VC_SAMPLE_QSUB, qt - q0);
-  uint64_t* sq = (uint64_t*)smem;                                      // [nq][W]
-  uint32_t* lh = (uint32_t*)(smem + (size_t)VC_SAMPLE_QSUB * W * 8);   // [nq][hs]
-  uint32_t* sthr = lh + (size_t)VC_SAMPLE_QSUB * hs;                   // [nq] only distances <= thr are counted
-  for (uint32_t i = threadIdx.x; i < nq * W; i += blockDim.x) sq[i] = queries[(uint64_t)q0 * W + i];
-  for (uint32_t i = threadIdx.x; i < nq * hs; i += blockDim.x) lh[i] = 0;
-  for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) sthr[i] = thr ? thr[q0 + i] : 0xFFFFFFFFu;
-  __syncthreads();
-
-  const uint64_t npairs = (s_items + 1) / 2;
-  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (uint64_t)gridDim.x * blockDim.x) {
-    uint64_t a[W], b[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const vc_u64x2 v = *reinterpret_cast<const vc_u64x2*>(cols + j * stride + 2 * p);
-      a[j] = v.x;
-      b[j] = v.y;
-    }
-    const bool vb = (2 * p + 1) < s_items;
-    for (uint32_t q = 0; q < nq; ++q) {
-      uint64_t qw[W];
-#pragma unroll
-      for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
-      const uint32_t t = sthr[q];
-      const uint32_t da = vc_dist<W>(a, qw), db = vc_dist<W>(b, qw);
-      if (da <= t) atomicAdd(&lh[q * hs + da], 1u);
-      if (vb && db <= t) atomicAdd(&lh[q * hs + db], 1u);
-    }
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < nq * hs; i += blockDim.x) {
-    const uint32_t c = lh[i];
-    if (c) atomicAdd(&shist[(uint64_t)q0 * hs + i], c);
-  }
-}
-
-// tau[q] = smallest d with  sum_{d' <= d} hist[q][d'] >= k ;  bits (accept everything) if none.
-// One wave per query.
+// smallest d with  sum_{d' <= d} h[d'] >= k  (0xFFFFFFFF if the histogram holds fewer than k).  One wave.
 __device__ __forceinline__ uint32_t vc_hist_cut(const uint32_t* h, uint32_t nbins, uint32_t k, bool atomic_reads) {
   const uint32_t lane = vc_lane();
   const uint32_t bpl = (nbins + VC_WAVE - 1) / VC_WAVE;  // consecutive bins per lane
@@ -186,11 +142,78 @@ __device__ __forceinline__ uint32_t vc_hist_cut(const uint32_t* h, uint32_t nbin
   return vc_wave_min(cand);
 }
 
+struct VcSampleParams {
+  const uint64_t* cols;
+  uint64_t stride;
+  uint64_t s_items;          // histogram the first s_items codes
+  const uint64_t* queries;   // [qt][W]
+  uint32_t* shist;           // [qt][hs] zeroed by the caller
+  const uint32_t* tau;       // [qt] refine: only distances <= tau[q] are counted
+  uint32_t qt, hs, refine;
+};
+
+// Stage kernel of the threshold bootstrap.  Blocks histogram their share of the prefix in LDS and flush with one
+// global atomic per non-empty bin; vc_tau_init_kernel turns the finished histogram into the threshold.
+template <int W>
+__global__ void __launch_bounds__(256) vc_sample_hist_kernel(const VcSampleParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t q0 = blockIdx.y * VC_SAMPLE_QSUB;
+  const uint32_t nq = min((uint32_t)VC_SAMPLE_QSUB, p.qt - q0);
+  const uint32_t hs = p.hs;
+  uint64_t* sq = (uint64_t*)smem;                                      // [nq][W]
+  uint32_t* lh = (uint32_t*)(smem + (size_t)VC_SAMPLE_QSUB * W * 8);   // [nq][hs]
+  uint32_t* sthr = lh + (size_t)VC_SAMPLE_QSUB * hs;                   // [nq] only distances <= thr are counted
+  for (uint32_t i = threadIdx.x; i < nq * W; i += blockDim.x) sq[i] = p.queries[(uint64_t)q0 * W + i];
+  for (uint32_t i = threadIdx.x; i < nq * hs; i += blockDim.x) lh[i] = 0;
+  for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) sthr[i] = p.refine ? p.tau[q0 + i] : 0xFFFFFFFFu;
+  __syncthreads();
+
+  const uint64_t npairs = (p.s_items + 1) / 2;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  // two item pairs per lane per round: 2*W 16-byte loads in flight
+  for (uint64_t pr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; pr < npairs; pr += 2 * step) {
+    uint64_t it[4][W];
+    const uint64_t p2 = pr + step < npairs ? pr + step : pr;   // clamp: the duplicate is masked out below
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const vc_u64x2 v0 = *reinterpret_cast<const vc_u64x2*>(p.cols + j * p.stride + 2 * pr);
+      const vc_u64x2 v1 = *reinterpret_cast<const vc_u64x2*>(p.cols + j * p.stride + 2 * p2);
+      it[0][j] = v0.x;
+      it[1][j] = v0.y;
+      it[2][j] = v1.x;
+      it[3][j] = v1.y;
+    }
+    bool ok[4];
+    ok[0] = true;
+    ok[1] = (2 * pr + 1) < p.s_items;
+    ok[2] = pr + step < npairs;
+    ok[3] = ok[2] && (2 * p2 + 1) < p.s_items;
+    for (uint32_t q = 0; q < nq; ++q) {
+      uint64_t qw[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
+      const uint32_t t = sthr[q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t d = vc_dist<W>(it[i], qw);
+        if (ok[i] && d <= t) atomicAdd(&lh[q * hs + d], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nq * hs; i += blockDim.x) {
+    const uint32_t c = lh[i];
+    if (c) atomicAdd(&p.shist[(uint64_t)q0 * hs + i], c);
+  }
+}
+
+// tau[q] = smallest d with cumulative count >= k.  First stage without a cut (fewer than k samples) = accept
+// everything; refining stage without a cut = keep the previous bound.  One wave per query.  (A "last block to
+// arrive" epilogue in the stage kernel was tried instead of this launch: 2048 tickets on one counter cost 0.1 ms.)
 __global__ void __launch_bounds__(64) vc_tau_init_kernel(const uint32_t* __restrict__ shist, uint32_t hs, uint32_t k,
                                                          uint32_t bits, uint32_t* __restrict__ tau, uint32_t refine) {
   const uint32_t q = blockIdx.x;
   const uint32_t cut = vc_hist_cut(shist + (uint64_t)q * hs, bits + 1, k, false);
-  // first stage: no cut (fewer than k samples) means "accept everything"; refining stage: keep the previous bound
   if (threadIdx.x == 0) tau[q] = (cut == 0xFFFFFFFFu) ? (refine ? tau[q] : bits) : (refine ? min(cut, tau[q]) : cut);
 }
 
@@ -640,16 +663,20 @@ hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t
 
 hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
-                                 const uint32_t* d_thr, uint32_t n_cu, hipStream_t s) {
-  if (s_items == 0 || qt == 0) return hipSuccess;
+                                 uint32_t k, uint32_t bits, uint32_t* d_tau, bool refine, uint32_t n_cu, hipStream_t s) {
+  if (qt == 0) return hipSuccess;
+  if (s_items == 0) {   // nothing to sample: the cut of the (zero) histogram = "accept everything"
+    hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u);
+    return hipGetLastError();
+  }
   const uint32_t gy = (qt + VC_SAMPLE_QSUB - 1) / VC_SAMPLE_QSUB;
-  const uint64_t npairs = (s_items + 1) / 2;
-  const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * 8);
+  const uint64_t npairs = std::max<uint64_t>((s_items + 1) / 2, 1);
+  const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 511) / 512, (uint64_t)n_cu * 8);
   const size_t lds = (size_t)VC_SAMPLE_QSUB * W * 8 + (size_t)VC_SAMPLE_QSUB * hist_stride * 4 + VC_SAMPLE_QSUB * 4;
-#define VC_SH_CASE(W_)                                                                                         \
-  case W_:                                                                                                     \
-    hipLaunchKernelGGL((vc_sample_hist_kernel<W_>), dim3(gx, gy), dim3(256), lds, s, cols, stride, s_items,     \
-                       d_queries, qt, d_shist, hist_stride, d_thr);                                            \
+  VcSampleParams p{cols, stride, s_items, d_queries, d_shist, d_tau, qt, hist_stride, refine ? 1u : 0u};
+#define VC_SH_CASE(W_)                                                                                   \
+  case W_:                                                                                               \
+    hipLaunchKernelGGL((vc_sample_hist_kernel<W_>), dim3(gx, gy), dim3(256), lds, s, p);                  \
     break;
   switch (W) {
     VC_SH_CASE(1)
@@ -660,12 +687,8 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
       return hipErrorInvalidValue;
   }
 #undef VC_SH_CASE
-  return hipGetLastError();
-}
-
-hipError_t vc_launch_tau_init(const uint32_t* d_shist, uint32_t hist_stride, uint32_t qt, uint32_t k, uint32_t bits,
-                              uint32_t* d_tau, bool refine, hipStream_t s) {
-  if (qt == 0) return hipSuccess;
+  hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return r;
   hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u);
   return hipGetLastError();
 }
