@@ -118,3 +118,37 @@ def test_code_and_bitmap_file_formats(vc, oracle, tmp_path):
             keys = {int.from_bytes(bytes(c[2 * t:2 * t + 2]), "little") for c in codes}
             got = {w * 32 + b for w in np.nonzero(words)[0] for b in range(32) if (int(words[w]) >> b) & 1}
             assert got == keys
+
+
+def test_gpu_proxy_behaves_like_a_base_proxy(oracle, tmp_path):
+    """vc::GpuProxy (verticut_host.hpp) through a C++ caller: put(ID,BinaryCode), get(HashIndex,Image_List),
+    get(ID,BinaryCode) with the reference's return codes (base_proxy.h:10-13)."""
+    n, bits, m = 3000, 128, 4
+    codes = oracle.gen_codes(n, bits, 21, kind=1, n_centres=12, max_flips=2)
+    (tmp_path / "lsh.code").write_bytes(codes.tobytes())
+    exe = tmp_path / "proxy_dump"
+    lib = os.path.join(ROOT, "verticut_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-o", str(exe), os.path.join(ROOT, "tests", "cpp", "proxy_dump.cc"),
+                           "-I", os.path.join(ROOT, "verticut_amd", "host"), "-L", lib, "-lverticut_gpu",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    probes = [(t, mo.key(codes[i], t)) for t, i in ((0, 5), (1, 77), (2, 1234), (3, 2999))] + [(0, 123456789)]
+    args = [str(x) for p in probes for x in p]
+    p = subprocess.run([str(exe), str(tmp_path / "lsh.code"), str(n), str(bits), str(m)] + args,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    out = p.stdout
+    assert "put_out_of_order 1" in out                      # PROXY_PUT_FAIL
+    blocks = re.split(r"^bucket ", out, flags=re.M)[1:]
+    for (t, idx), blk in zip(probes, blocks):
+        head = blk.splitlines()[0]
+        exp = mo.bucket(t, idx)
+        if len(exp) == 0:
+            assert head == "%d %d rc=1 n=0" % (t, idx)      # PROXY_NOT_FOUND
+            continue
+        assert head == "%d %d rc=0 n=%d" % (t, idx, len(exp))
+        rows = re.findall(r"^  (\d+) ([0-9a-f]+)$", blk, flags=re.M)
+        assert [int(a) for a, _ in rows] == list(exp)
+        assert all(bytes.fromhex(h) == codes[int(a)].tobytes() for a, h in rows)
+    assert ("get_id7 rc=0 " + codes[7].tobytes().hex()) in out
+    assert "get_missing rc=1" in out
