@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=float, default=1e9, help="database size (total over all GPUs)")
+    ap.add_argument("--db-size", dest="n", type=float, default=1e9, help="database size (total over all GPUs)")
     ap.add_argument("--bits", type=int, default=128)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--queries", type=int, default=8, help="queries per step (= one query tile = one DB pass)")
@@ -97,15 +97,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
+    # rehearsal knobs (dev only): run the multi-rank flow on ONE GPU, where RCCL cannot be used (one device per rank)
+    backend = os.environ.get("VC_BENCH_BACKEND", "nccl")
+    if os.environ.get("VC_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     n_total = int(args.n)
     Q, k = args.queries, args.k
-    ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=local_rank, query_tile=Q, pipelined=True)
+    ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=local_rank, query_tile=Q)
     ss.add_synthetic(args.seed)
 
     # query batches resident in HBM: uniform random codes = worst case (no early threshold help)
@@ -115,18 +122,32 @@ def main():
     dev_q = [torch.from_numpy(h).to(device) for h in host_q]
     torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        ss.search(dev_q[i % nb], k)
+    def run_steps(count):
+        res = None
+        for i in range(count):
+            res = ss.search(dev_q[i % nb], k)
+        ss.flush()                  # N > 1, pipelined exchange: the last batches' side-stream work joins this stream
+        return res
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
+    exchange = "none"
+    if world > 1:
+        # The per-batch exchange (all-gather + merge) runs inline on the step's stream: the plain, widely used pattern.
+        # VC_BENCH_PIPELINED=1 moves it to a side stream under the next batch's scan (ShardedSearch(pipelined=True));
+        # that path is covered by tests but has never run over RCCL on a multi-GPU node, so it is opt-in.
+        ss.pipelined = os.environ.get("VC_BENCH_PIPELINED") == "1"
+        exchange = "side-stream" if ss.pipelined else "inline"
+        if ss.pipelined:
+            run_steps(2)
+            torch.cuda.synchronize()
     ss.backend.timing()  # drop warm-up event records
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out, cnt = ss.search(dev_q[i % nb], k)
-    ss.flush()                      # N > 1: exchanges of the last batches (side stream) join the main stream
+    out, cnt = run_steps(args.steps)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     if world > 1:
@@ -144,14 +165,23 @@ def main():
         # packed values, k results, every reported distance recomputed from the stored code.
         res = out.cpu().numpy().view(np.uint64)
         qh = host_q[(args.steps - 1) % nb]
-        ok = bool(np.all(cnt.cpu().numpy() == min(k, n_total)) and np.all(res[:, 1:] > res[:, :-1]))
+        why = []
+        if not np.all(cnt.cpu().numpy() == min(k, n_total)):
+            why.append("counts %s" % cnt.cpu().numpy().tolist())
+        if not np.all(res[:, 1:] > res[:, :-1]):
+            why.append("rows not strictly ascending")
         for qi in range(min(Q, 2)):
             for j in (0, k // 2, k - 1):
                 gid = int(res[qi, j] & np.uint64(0xFFFFFFFF))
                 if ss.lo <= gid < ss.hi:
                     code = ss.backend.engine.get_code(gid)
                     d = int(np.unpackbits(np.bitwise_xor(code, qh[qi])).sum())
-                    ok = ok and d == int(res[qi, j] >> np.uint64(32))
+                    if d != int(res[qi, j] >> np.uint64(32)):
+                        why.append("query %d result %d: id %d reported %d, stored code says %d"
+                                   % (qi, j, gid, int(res[qi, j] >> np.uint64(32)), d))
+        ok = not why
+        if why:
+            sys.stderr.write("[bench rank %d] results check failed: %s\n" % (rank, "; ".join(why[:4])))
         if world > 1:
             okt = torch.tensor([1 if ok else 0], device=device)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
@@ -191,6 +221,7 @@ def main():
                 "query_kind": "uniform random", "seed": args.seed,
                 "parallelism": "1 process/GPU, DB shard per GPU, RCCL all-gather of per-shard top-k + merge kernel"
                                if world > 1 else "single GPU",
+                "exchange": exchange,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

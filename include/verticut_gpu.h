@@ -61,6 +61,11 @@ extern "C" {
 #define VC_SYNTH_UNIFORM 0
 #define VC_SYNTH_CLUSTERED 1
 
+/* ---- streams: every `stream` argument is a hipStream_t; NULL is the HIP null (legacy default) stream -- what
+ * PyTorch-ROCm's default stream is -- and VC_STREAM_OWN names the engine's private non-blocking stream, on which
+ * the host-pointer calls run unless vc_set_stream says otherwise. */
+#define VC_STREAM_OWN ((void*)(intptr_t)-1)
+
 /* ---- output order for k-NN results */
 #define VC_ORDER_ASCENDING 0       /* canonical: ascending packed (dist, id) */
 #define VC_ORDER_FARTHEST_FIRST 1  /* as SearchWorker::find / linear_search print (search_worker.cc:210-216) */
@@ -158,7 +163,8 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
                   uint64_t* out, uint32_t* counts, vc_query_stats* stats);
 /* Device-pointer variant for callers that keep queries/results in HBM (torch / multi-GPU merge).
  * d_queries: nq*bits/8 bytes; d_out: nq*k uint64, ascending, padded with UINT64_MAX; d_counts: nq uint32.
- * Asynchronous on `stream` (a hipStream_t) when mode == VC_MODE_LINEAR; other modes synchronise.
+ * Asynchronous on `stream` and ordered like any other work enqueued there when mode == VC_MODE_LINEAR; other
+ * modes synchronise that stream.
  * LINEAR cannot recover from a candidate-ring overflow without a host round trip: such a query reports
  * d_counts[i] == UINT32_MAX (its row is then only an upper bound) and should be re-run through vc_search_knn. */
 int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode,
@@ -181,7 +187,7 @@ int vc_merge_topk_dev(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, ui
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Sums and resets the event records (synchronises with the last recorded call). */
 int vc_get_timing(const vc_engine* e, vc_timing* t);
-/* Bind the engine's work to a caller-owned stream (hipStream_t); NULL = engine's own stream. */
+/* Stream of the host-pointer calls (default VC_STREAM_OWN). */
 int vc_set_stream(vc_engine* e, void* stream);
 
 #ifdef __cplusplus

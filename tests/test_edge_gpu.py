@@ -139,3 +139,32 @@ def test_device_api_matches_host_api(vc, oracle):
         assert np.array_equal(out.cpu().numpy().view(np.uint64), host) and np.array_equal(cnt.cpu().numpy(), hcnt)
         t = e.timing()
         assert t.calls == 2 and t.scan_launches == 2
+
+
+def test_device_api_is_ordered_on_the_callers_stream(vc):
+    """results of vc_search_knn_dev must be visible to later work on the SAME stream without any host sync
+    (the multi-GPU exchange reads them from the stream right away), on the null stream and on a side stream."""
+    import torch
+    n, bits, k = 60_000_000, 128, 50                     # ~0.25 ms of scan: long enough for a race to show
+    rng = np.random.default_rng(8)
+    q1 = rng.integers(0, 256, size=(8, 16), dtype=np.uint8)
+    q2 = rng.integers(0, 256, size=(8, 16), dtype=np.uint8)
+    with vc.Engine(bits, capacity=n, query_tile=8) as e:
+        e.add_synthetic(n, seed=34)
+        ref1, _ = e.search_knn(q1, k)
+        ref2, _ = e.search_knn(q2, k)
+        d1, d2 = torch.from_numpy(q1).cuda(), torch.from_numpy(q2).cuda()
+        out = torch.zeros((8, k), dtype=torch.int64, device="cuda")
+        cnt = torch.zeros((8,), dtype=torch.int32, device="cuda")
+        for stream in (torch.cuda.current_stream(), torch.cuda.Stream()):
+            with torch.cuda.stream(stream):
+                for dq, ref in ((d1, ref1), (d2, ref2), (d1, ref1)):
+                    e.search_knn_dev(dq.data_ptr(), 8, k, out.data_ptr(), cnt.data_ptr(), stream=stream.cuda_stream)
+                    snap = out.clone()                   # torch op on the same stream, no synchronisation in between
+                    stream.synchronize()
+                    assert np.array_equal(snap.cpu().numpy().view(np.uint64), ref)
+        # a host-API call right after an un-synchronised device-API call must not trample the shared work buffers
+        e.search_knn_dev(d2.data_ptr(), 8, k, out.data_ptr(), cnt.data_ptr(), stream=None)
+        again, _ = e.search_knn(q1, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(again, ref1) and np.array_equal(out.cpu().numpy().view(np.uint64), ref2)

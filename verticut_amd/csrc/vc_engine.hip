@@ -35,6 +35,8 @@ struct vc_engine {
   size_t ev_used = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_calls, ev_scans;
   hipEvent_t cur_t0 = nullptr;
+  hipEvent_t last_call = nullptr;   // end of the most recent search call: the next call (any stream) waits for it,
+  bool last_call_valid = false;     // because all calls share the engine's work buffers
   uint64_t scan_bytes = 0;
   vc_timing last{};
 
@@ -173,6 +175,7 @@ int vc_destroy(vc_engine* e) {
   (void)hipFree(e->d_out);
   (void)hipFree(e->d_cnt);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  if (e->last_call) (void)hipEventDestroy(e->last_call);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
   return VC_OK;
@@ -180,7 +183,7 @@ int vc_destroy(vc_engine* e) {
 
 int vc_set_stream(vc_engine* e, void* stream) {
   if (!e) return VC_ERR_INVALID;
-  e->stream = stream ? (hipStream_t)stream : e->own_stream;
+  e->stream = stream == VC_STREAM_OWN ? e->own_stream : (hipStream_t)stream;   // NULL = the HIP null stream
   return VC_OK;
 }
 
@@ -325,10 +328,13 @@ static int ev_pair(vc_engine* e, hipEvent_t* a, hipEvent_t* b) {
   return VC_OK;
 }
 static void timing_begin(vc_engine* e) {
+  if (e->last_call_valid) (void)hipStreamWaitEvent(e->stream, e->last_call, 0);
   e->cur_t0 = ev_take(e);
   if (e->cur_t0) (void)hipEventRecord(e->cur_t0, e->stream);
 }
 static void timing_end(vc_engine* e) {
+  if (!e->last_call && hipEventCreateWithFlags(&e->last_call, hipEventDisableTiming) != hipSuccess) e->last_call = nullptr;
+  if (e->last_call) e->last_call_valid = hipEventRecord(e->last_call, e->stream) == hipSuccess;
   if (!e->cur_t0) return;
   hipEvent_t t1 = ev_take(e);
   if (!t1) { --e->ev_used; e->cur_t0 = nullptr; return; }
@@ -528,7 +534,7 @@ int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t
   if (!d_out) return VC_ERR_INVALID;
   if ((rc = bind_device(e))) return rc;
   hipStream_t saved = e->stream;
-  if (stream) e->stream = (hipStream_t)stream;
+  e->stream = stream == VC_STREAM_OWN ? e->own_stream : (hipStream_t)stream;   // NULL = the HIP null stream
   if ((rc = grow(e, &e->d_cnt, &e->cnt_bytes, (size_t)nq * 8))) { e->stream = saved; return rc; }
   timing_begin(e);
   if (mode == VC_MODE_LINEAR) {

@@ -19,6 +19,7 @@ FLAG_USE_BITMAP, FLAG_REF_SIGNEXT_KEYS, FLAG_REF_STOP_LITERAL4 = 1, 2, 4
 SYNTH_UNIFORM, SYNTH_CLUSTERED = 0, 1
 ORDER_ASCENDING, ORDER_FARTHEST_FIRST = 0, 1
 PACK_INF = np.uint64(0xFFFFFFFFFFFFFFFF)
+STREAM_OWN = C.c_void_p(-1)   # VC_STREAM_OWN; None / 0 = the HIP null stream (PyTorch's default stream)
 
 # every symbol include/verticut_gpu.h declares (tests check the .so exports exactly these)
 EXPORTS = [
@@ -238,7 +239,9 @@ class Engine:
         return out, counts
 
     def search_knn_dev(self, d_queries, nq, k, d_out, d_counts=None, mode=MODE_LINEAR, stream=None):
-        """Device-pointer variant: arguments are raw device addresses (ints), e.g. tensor.data_ptr()."""
+        """Device-pointer variant: arguments are raw device addresses (ints), e.g. tensor.data_ptr().
+        stream: raw hipStream_t (torch.cuda.current_stream().cuda_stream); None/0 = the null stream, which is
+        PyTorch's default stream, so the call is ordered with torch work either way."""
         self._check(self._L.vc_search_knn_dev(self._h, d_queries, nq, k, mode, d_out, d_counts, stream))
 
     def search_radius(self, queries, radius, mode=MODE_LINEAR, cap_per_query=4096):
