@@ -445,6 +445,7 @@ struct VcListsSrc {
 };
 
 #define VC_SEL_THREADS 1024
+#define VC_RANK_SORT_MAX 1024u
 
 __device__ __forceinline__ void vc_bitonic_lds(uint64_t* a, uint32_t P) {
   for (uint32_t size = 2; size <= P; size <<= 1) {
@@ -558,12 +559,33 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
     while (P < fill) P <<= 1;
     for (uint32_t i = fill + threadIdx.x; i < P; i += VC_SEL_THREADS) a[i] = VC_PACK_INF;
   }
-  vc_bitonic_lds(a, P);
+  // Small survivor sets (the usual case: a few hundred entries) are ordered by counting: entry i goes to slot
+  // #{j : a[j] < a[i]} -- packed values are distinct -- which is P broadcast LDS reads per thread and one barrier
+  // instead of the ~log^2 P barriers of the bitonic network.
+  __shared__ uint64_t srt[VC_RANK_SORT_MAX];
+  const uint64_t* sorted = a;
+  if (P <= VC_RANK_SORT_MAX) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < P; i += VC_SEL_THREADS) {
+      const uint64_t v = a[i];
+      uint32_t r = 0;
+      if (v != VC_PACK_INF) {
+        for (uint32_t j = 0; j < P; ++j) r += a[j] < v;
+      } else {
+        r = i;   // padding sits at the tail of a[] already (index >= fill) and stays there
+      }
+      srt[r] = v;
+    }
+    __syncthreads();
+    sorted = srt;
+  } else {
+    vc_bitonic_lds(a, P);
+  }
   if (threadIdx.x == 0) s_valid = 0;
   __syncthreads();
   uint32_t mine = 0;
   for (uint32_t i = threadIdx.x; i < k; i += VC_SEL_THREADS) {
-    const uint64_t v = i < P ? a[i] : VC_PACK_INF;
+    const uint64_t v = i < P ? sorted[i] : VC_PACK_INF;
     out[(uint64_t)q * k + i] = v;
     mine += v != VC_PACK_INF;
   }
