@@ -41,6 +41,7 @@ struct vc_engine {
   vc_timing last{};
 
   VcMihIndex* mih = nullptr;
+  VcRadiusWork radius_work;
   std::string err;
 };
 
@@ -167,6 +168,7 @@ int vc_destroy(vc_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
   if (e->mih) vc_mih_free(e->mih);
+  vc_radius_work_free(&e->radius_work);
   (void)hipFree(e->d_cols);
   (void)hipFree(e->d_stage);
   (void)hipFree(e->d_q);
@@ -672,7 +674,7 @@ int vc_search_radius(vc_engine* e, const void* queries, uint32_t nq, uint32_t ra
   VC_HIP(e, hipMemcpyAsync(e->d_q, queries, qbytes, hipMemcpyHostToDevice, e->stream));
   timing_begin(e);
   rc = vc_radius_search(e->mih, mode == VC_MODE_MIH_EXACT, e->d_cols, e->stride, e->n, e->W, e->cfg.id_base, e->n_cu,
-                        e->d_q, nq, radius, out, out_cap, out_offsets, e->stream, &e->err);
+                        e->d_q, nq, radius, out, out_cap, out_offsets, &e->radius_work, e->stream, &e->err);
   timing_end(e);
   return rc;
 }

@@ -808,9 +808,15 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
 }
 
 // ---- fixed-radius neighbour search (BASELINE config 2) ----------------------------------------------------
+void vc_radius_work_free(VcRadiusWork* w) {
+  if (!w) return;
+  (void)hipFree(w->d_ring); (void)hipFree(w->d_sorted); (void)hipFree(w->d_compact); (void)hipFree(w->d_aux); (void)hipFree(w->d_temp);
+  *w = VcRadiusWork();
+}
+
 int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W,
                      uint32_t id_base, uint32_t n_cu, const uint64_t* d_q, uint32_t nq, uint32_t radius, uint64_t* out,
-                     uint64_t out_cap, uint64_t* out_offsets, hipStream_t s, std::string* err) {
+                     uint64_t out_cap, uint64_t* out_offsets, VcRadiusWork* wk, hipStream_t s, std::string* err) {
   if (use_mih && n != ix->n) {
     if (err) *err = "index is stale: codes were added after vc_build_index()";
     return VC_ERR_STATE;
@@ -820,18 +826,27 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
   const uint32_t bits = W * 64;
   if (radius > bits) radius = bits;
   const uint32_t TQ = use_mih ? MIH_QTILE : 64u;
-  uint32_t cap = use_mih ? std::max(ix->cap, 4096u) : 65536u;
+  uint32_t cap = std::max(wk->cap, use_mih ? std::max(ix->cap, 4096u) : 65536u);
+  if (wk->tq != TQ) {   // tile shape changed (scan <-> MIH): start over with fresh buffers
+    vc_radius_work_free(wk);
+    wk->tq = TQ;
+  }
   std::vector<uint64_t> result;
   std::vector<uint64_t> offs(nq + 1, 0);
 
-  uint64_t* d_ring = nullptr;
-  uint64_t* d_sorted = nullptr;
-  uint64_t* d_compact = nullptr;
-  uint64_t compact_cap = 0;
-  uint32_t* d_aux = nullptr;     // count[TQ] | tau[TQ] | hist(dummy)[TQ*8] | beg[TQ] | end[TQ]
-  void* d_temp = nullptr;
-  size_t temp_bytes = 0;
-  auto cleanup = [&]() { (void)hipFree(d_ring); (void)hipFree(d_sorted); (void)hipFree(d_compact); (void)hipFree(d_aux); (void)hipFree(d_temp); };
+  // work buffers live in *wk across calls (references so the retry logic below can replace them)
+  uint64_t*& d_ring = wk->d_ring;
+  uint64_t*& d_sorted = wk->d_sorted;
+  uint64_t*& d_compact = wk->d_compact;
+  uint64_t& compact_cap = wk->compact_cap;
+  uint32_t*& d_aux = wk->d_aux;     // count[TQ] | tau[TQ] | beg[TQ] | end[TQ] | hist[TQ*hs]
+  void*& d_temp = wk->d_temp;
+  size_t& temp_bytes = wk->temp_bytes;
+  if (wk->cap != cap) {             // ring size changed: both rings and the sort workspace are re-made below
+    (void)hipFree(d_ring); (void)hipFree(d_sorted);
+    d_ring = d_sorted = nullptr;
+  }
+  auto cleanup = [&]() {};          // buffers stay with the engine
 #define R_CHECK(call)                                                      \
   do {                                                                     \
     hipError_t _r = (call);                                                \
@@ -843,7 +858,12 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
   } while (0)
 
   const uint32_t hs = (bits + 1 + 7) & ~7u;
-  R_CHECK(hipMalloc((void**)&d_aux, (size_t)TQ * (4 + hs) * 4));
+  if (wk->aux_words < (size_t)TQ * (4 + hs)) {
+    (void)hipFree(d_aux);
+    d_aux = nullptr;
+    R_CHECK(hipMalloc((void**)&d_aux, (size_t)TQ * (4 + hs) * 4));
+    wk->aux_words = (size_t)TQ * (4 + hs);
+  }
   uint32_t* d_count = d_aux;
   uint32_t* d_tau = d_aux + TQ;
   uint32_t* d_beg = d_aux + 2 * TQ;
@@ -858,6 +878,7 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
       if (!d_ring) {
         R_CHECK(hipMalloc((void**)&d_ring, (size_t)TQ * cap * 8));
         R_CHECK(hipMalloc((void**)&d_sorted, (size_t)TQ * cap * 8));
+        wk->cap = cap;
         temp_bytes = 0;
         R_CHECK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, temp_bytes, d_ring, d_sorted, (int64_t)TQ * cap, (int)TQ,
                                                            d_beg, d_end, 0, 44, s));
@@ -934,7 +955,6 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
     }
   }
 #undef R_CHECK
-  cleanup();
   memcpy(out_offsets, offs.data(), (nq + 1) * sizeof(uint64_t));
   if (offs[nq] > out_cap) {
     if (err) *err = "radius search: output buffer too small (needed counts are in out_offsets)";

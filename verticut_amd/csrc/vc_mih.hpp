@@ -17,7 +17,18 @@ int vc_mih_bucket(VcMihIndex* ix, uint32_t table, uint32_t index, std::vector<ui
 int vc_mih_bitmap_test(VcMihIndex* ix, uint32_t table, uint32_t index, int* bit, hipStream_t s, std::string* err);
 int vc_mih_bitmap_read(VcMihIndex* ix, uint32_t table, uint64_t word_off, uint64_t n_words, uint32_t* out, hipStream_t s,
                        std::string* err);
+// grow-only device buffers of the radius search, owned by the engine (allocation costs more than a search)
+struct VcRadiusWork {
+  uint64_t *d_ring = nullptr, *d_sorted = nullptr, *d_compact = nullptr;
+  uint32_t* d_aux = nullptr;
+  void* d_temp = nullptr;
+  size_t temp_bytes = 0, aux_words = 0;
+  uint64_t compact_cap = 0;
+  uint32_t cap = 0, tq = 0;
+};
+void vc_radius_work_free(VcRadiusWork* w);
+
 // all items within full distance <= radius; ix may be null when use_mih is false (linear scan)
 int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W,
                      uint32_t id_base, uint32_t n_cu, const uint64_t* d_q, uint32_t nq, uint32_t radius, uint64_t* out,
-                     uint64_t out_cap, uint64_t* out_offsets, hipStream_t s, std::string* err);
+                     uint64_t out_cap, uint64_t* out_offsets, VcRadiusWork* work, hipStream_t s, std::string* err);
