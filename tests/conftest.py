@@ -22,7 +22,11 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def vc():
-    """The product binding; the library must exist (built by __graft_entry__.build())."""
+    """The product binding.  The library is normally there already (__graft_entry__.build()); on a box that only
+    received the sources it is compiled once here (hipcc cross-compiles gfx950 without a GPU)."""
+    from verticut_amd import build as vb
     from verticut_amd import engine
+    if not os.path.exists(engine.LIB_PATH) or not os.path.exists(vb.DRIVER):
+        vb.build(force=True)
     engine.load_library()
     return engine

@@ -22,7 +22,7 @@ def _run(args, env_extra=None):
     return p.stdout
 
 
-def test_driver_file_queries_match_oracle(oracle, tmp_path):
+def test_driver_file_queries_match_oracle(vc, oracle, tmp_path):
     assert os.path.exists(DRIVER), "build() must have produced the host driver"
     n, bits, m, k = 40000, 128, 4, 10
     rng = np.random.default_rng(21)
@@ -53,7 +53,7 @@ def test_driver_file_queries_match_oracle(oracle, tmp_path):
     assert (int(avg.group(1)), int(avg.group(3))) == (sub_sum // len(q), rad_sum // len(q))
 
 
-def test_driver_query_by_id(oracle, tmp_path):
+def test_driver_query_by_id(vc, oracle, tmp_path):
     """image_search_client::search_image_by_id: the path the reference ships dead (distributed_image_search.cc:116)."""
     n, bits, m, k = 20000, 128, 4, 5
     codes = oracle.gen_codes(n, bits, 7, kind=1, n_centres=100, max_flips=6)
@@ -65,7 +65,7 @@ def test_driver_query_by_id(oracle, tmp_path):
     assert pairs[-1][1] == 0 and (1234, 0) in pairs     # nearest last: the image itself at distance 0
 
 
-def test_accuracy_test_metrics(oracle, tmp_path):
+def test_accuracy_test_metrics(vc, oracle, tmp_path):
     """accuracy-test prints the reference's running metrics (accuracy_test.cc:88-91, 106-135)."""
     n, bits, m, k = 30000, 128, 4, 10
     rng = np.random.default_rng(33)
@@ -120,7 +120,7 @@ def test_code_and_bitmap_file_formats(vc, oracle, tmp_path):
             assert got == keys
 
 
-def test_gpu_proxy_behaves_like_a_base_proxy(oracle, tmp_path):
+def test_gpu_proxy_behaves_like_a_base_proxy(vc, oracle, tmp_path):
     """vc::GpuProxy (verticut_host.hpp) through a C++ caller: put(ID,BinaryCode), get(HashIndex,Image_List),
     get(ID,BinaryCode) with the reference's return codes (base_proxy.h:10-13)."""
     n, bits, m = 3000, 128, 4
