@@ -170,31 +170,31 @@ __global__ void __launch_bounds__(256) vc_sample_hist_kernel(const VcSampleParam
 
   const uint64_t npairs = (p.s_items + 1) / 2;
   const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-  // two item pairs per lane per round: 2*W 16-byte loads in flight
-  for (uint64_t pr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; pr < npairs; pr += 2 * step) {
-    uint64_t it[4][W];
-    const uint64_t p2 = pr + step < npairs ? pr + step : pr;   // clamp: the duplicate is masked out below
+  constexpr int NP = 1;   // item pairs per lane per round (more pairs cost occupancy: measured slower at 2 and 4)
+  for (uint64_t pr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; pr < npairs; pr += NP * step) {
+    uint64_t it[2 * NP][W];
+    bool ok[2 * NP];
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const vc_u64x2 v0 = *reinterpret_cast<const vc_u64x2*>(p.cols + j * p.stride + 2 * pr);
-      const vc_u64x2 v1 = *reinterpret_cast<const vc_u64x2*>(p.cols + j * p.stride + 2 * p2);
-      it[0][j] = v0.x;
-      it[1][j] = v0.y;
-      it[2][j] = v1.x;
-      it[3][j] = v1.y;
+    for (int g = 0; g < NP; ++g) {
+      const uint64_t pg = pr + g * step;
+      const bool in = pg < npairs;
+      const uint64_t pc = in ? pg : pr;              // clamp: the duplicate is masked out below
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const vc_u64x2 v = *reinterpret_cast<const vc_u64x2*>(p.cols + j * p.stride + 2 * pc);
+        it[2 * g][j] = v.x;
+        it[2 * g + 1][j] = v.y;
+      }
+      ok[2 * g] = in;
+      ok[2 * g + 1] = in && (2 * pc + 1) < p.s_items;
     }
-    bool ok[4];
-    ok[0] = true;
-    ok[1] = (2 * pr + 1) < p.s_items;
-    ok[2] = pr + step < npairs;
-    ok[3] = ok[2] && (2 * p2 + 1) < p.s_items;
     for (uint32_t q = 0; q < nq; ++q) {
       uint64_t qw[W];
 #pragma unroll
       for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
       const uint32_t t = sthr[q];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 2 * NP; ++i) {
         const uint32_t d = vc_dist<W>(it[i], qw);
         if (ok[i] && d <= t) atomicAdd(&lh[q * hs + d], 1u);
       }
@@ -693,7 +693,7 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
   }
   const uint32_t gy = (qt + VC_SAMPLE_QSUB - 1) / VC_SAMPLE_QSUB;
   const uint64_t npairs = std::max<uint64_t>((s_items + 1) / 2, 1);
-  const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 511) / 512, (uint64_t)n_cu * 8);
+  const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * 8);
   const size_t lds = (size_t)VC_SAMPLE_QSUB * W * 8 + (size_t)VC_SAMPLE_QSUB * hist_stride * 4 + VC_SAMPLE_QSUB * 4;
   VcSampleParams p{cols, stride, s_items, d_queries, d_shist, d_tau, qt, hist_stride, refine ? 1u : 0u};
 #define VC_SH_CASE(W_)                                                                                   \
