@@ -7,7 +7,7 @@
 
 #include <vector>
 
-#include "verticut_host.hpp"
+#include "verticut_wire.hpp"
 
 int main(int argc, char** argv) {
   if (argc < 7) return 2;
@@ -56,6 +56,23 @@ int main(int argc, char** argv) {
   printf("\n");
   id.set_id((uint32_t)n + 5);
   printf("get_missing rc=%d\n", proxy.get(id, code));
+  // byte-level KV view (what a memcached/redis/pilaf server would be asked): first probe as HashIndex bytes, id 7 as ID bytes
+  {
+    vc::HashIndex hi;
+    hi.set_table_id(atoi(argv[5]));
+    hi.set_index((uint32_t)strtoul(argv[6], nullptr, 10));
+    std::string val;
+    const int rc = vc::wire::kv_get(proxy, vc::wire::encode(hi), &val);
+    printf("kv_bucket rc=%d ", rc);
+    for (unsigned char c : val) printf("%02x", c);
+    printf("\n");
+    vc::ID k7;
+    k7.set_id(7);
+    val.clear();
+    printf("kv_id7 rc=%d ", vc::wire::kv_get(proxy, vc::wire::encode(k7), &val));
+    for (unsigned char c : val) printf("%02x", c);
+    printf("\n");
+  }
   proxy.close();
   return 0;
 }

@@ -152,3 +152,19 @@ def test_gpu_proxy_behaves_like_a_base_proxy(vc, oracle, tmp_path):
         assert all(bytes.fromhex(h) == codes[int(a)].tobytes() for a, h in rows)
     assert ("get_id7 rc=0 " + codes[7].tobytes().hex()) in out
     assert "get_missing rc=1" in out
+
+    # serialized KV view == protobuf bytes of the same records (image_search.proto:11-26)
+    def varint(v):
+        b = bytearray()
+        while v >= 0x80:
+            b.append((v & 0x7F) | 0x80)
+            v >>= 7
+        b.append(v)
+        return bytes(b)
+    t0, idx0 = probes[0]
+    exp_list = b""
+    for gid in mo.bucket(t0, idx0):
+        pair = b"\x08" + varint(int(gid)) + b"\x12" + varint(16) + codes[int(gid)].tobytes()
+        exp_list += b"\x0a" + varint(len(pair)) + pair
+    assert ("kv_bucket rc=0 " + exp_list.hex()) in out
+    assert ("kv_id7 rc=0 " + (b"\x0a" + varint(16) + codes[7].tobytes()).hex()) in out

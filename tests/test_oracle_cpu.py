@@ -220,3 +220,31 @@ def test_oracle_reproduces_search_fixtures(oracle):
                 e = fx["mih_exact"][i]
                 assert (st.radius, st.n_sub_reads, st.n_distinct) == (e["radius"], e["n_sub_reads"], e["n_candidates"])
                 assert sorted(int(v) >> 32 for v in res) == [v >> 32 for v in e["result"]]
+
+
+# ----------------------------------------------------------------------------- protobuf wire records (host layer)
+def _varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def test_wire_encoding_matches_proto2(tmp_path):
+    """verticut_wire.hpp writes the bytes protobuf would for image_search.proto:3-27 (SURVEY.md appendix A.11);
+    the expected strings are assembled here independently from the proto2 wire rules."""
+    import subprocess
+    exe = tmp_path / "wire_test"
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-o", str(exe), os.path.join(ROOT, "tests", "cpp", "wire_test.cc"),
+                           "-I", os.path.join(ROOT, "verticut_amd", "host")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    got = dict(l.split(" ", 1) for l in out.strip().splitlines())
+    code = b"0123456789123456"
+    pair = lambda i: b"\x08" + _varint(i) + b"\x12" + _varint(len(code)) + code   # noqa: E731
+    assert got["id"] == (b"\x08" + _varint(300)).hex()
+    assert got["hashindex"] == (b"\x08" + _varint(3) + b"\x10" + _varint(0xFFFF8001)).hex()
+    assert got["binarycode"] == (b"\x0a" + _varint(16) + code).hex()
+    assert got["imagelist"] == b"".join(b"\x0a" + _varint(len(pair(i))) + pair(i) for i in (0, 1000000, 2000000)).hex()
+    assert got["roundtrip"] == "ok"
