@@ -85,6 +85,12 @@ def cpu_baseline(args, n_total):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL writes a five-line version
+    # banner when its communicator comes up), so fd 1 is pointed at stderr for the whole run and the JSON line goes to
+    # a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from verticut_amd import engine as vc
@@ -112,7 +118,13 @@ def main():
 
     n_total = int(args.n)
     Q, k = args.queries, args.k
-    ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=local_rank, query_tile=Q)
+    force_exchange = world == 1 and os.environ.get("VC_BENCH_FORCE_EXCHANGE") == "1"   # dev: RCCL exchange with one rank
+    if force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": device} if backend == "nccl" else {}))
+    ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=local_rank, query_tile=Q,
+                       force_exchange=force_exchange)
     ss.add_synthetic(args.seed)
 
     # query batches resident in HBM: uniform random codes = worst case (no early threshold help)
@@ -132,7 +144,7 @@ def main():
     run_steps(args.warmup)
     torch.cuda.synchronize()
     exchange = "none"
-    if world > 1:
+    if world > 1 or force_exchange:
         # The per-batch exchange (all-gather + merge) runs inline on the step's stream: the plain, widely used pattern.
         # VC_BENCH_PIPELINED=1 moves it to a side stream under the next batch's scan (ShardedSearch(pipelined=True));
         # that path is covered by tests but has never run over RCCL on a multi-GPU node, so it is opt-in.
@@ -233,7 +245,8 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, n_total)
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     ss.close()
     if world > 1:
         dist.destroy_process_group()

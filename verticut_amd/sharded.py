@@ -59,11 +59,12 @@ class ShardedSearch:
     """
 
     def __init__(self, bits, total_n, rank=None, world=None, n_tables=0, device=None, group=None, backend=None,
-                 pipelined=False, **engine_kw):
+                 pipelined=False, force_exchange=False, **engine_kw):
         """pipelined=True: the all-gather + merge of batch i run on a side stream while batch i+1 is already being
         scanned; results of a call are then ordered on the caller's stream only after flush() (or two calls later)."""
         self.group = group
         self.pipelined = pipelined
+        self.force_exchange = force_exchange   # run the all-gather + merge even with one rank (exercises RCCL on 1 GPU)
         self._side = None
         self._sets = [None, None]
         self._done = [None, None]
@@ -142,12 +143,12 @@ class ShardedSearch:
                 torch.cuda.current_stream().wait_event(ev)
 
     def search(self, queries, k, mode=vc.MODE_LINEAR):
-        if self.pipelined and self.world > 1 and queries.is_cuda:
+        if self.pipelined and (self.world > 1 or self.force_exchange) and queries.is_cuda:
             return self._search_pipelined(queries, k, mode)
         nq = queries.shape[0]
         local, lcnt, gath, out, ocnt = self._buffers(nq, k, queries.device)
         self.backend.local_topk(queries, k, local, lcnt, mode)
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return local, lcnt
         # the only exchange step of the path: nq*k*8 bytes per rank
         dist.all_gather_into_tensor(gath.view(self.world * nq, k), local, group=self.group)  # rank-major concat
