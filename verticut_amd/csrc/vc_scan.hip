@@ -25,6 +25,14 @@
 #ifndef VC_SCAN_NT
 #define VC_SCAN_NT 1
 #endif
+// waves per SIMD the 256-thread variants must leave room for (3 -> up to 168 VGPRs, 4 -> 128)
+#ifndef VC_SCAN_MIN_WAVES
+#define VC_SCAN_MIN_WAVES 4
+#endif
+// software-pipeline the LDS query reads through two register sets (costs 2*W+2 VGPRs)
+#ifndef VC_SCAN_QUERY_PREFETCH
+#define VC_SCAN_QUERY_PREFETCH 1
+#endif
 #if VC_SCAN_NT
 #define VC_SCAN_LOAD(ptr) __builtin_nontemporal_load(ptr)
 #else
@@ -236,13 +244,31 @@ __global__ void __launch_bounds__(64) vc_tau_init_kernel(const uint32_t* __restr
 // re-derive tau from it (smallest d whose cumulative count reaches k).  tau only ever decreases and a
 // stale tau is merely conservative, so no ordering between waves is needed for correctness.
 // ------------------------------------------------------------------------------------------
+// Rare path of the verify kernel (a lane beat the threshold).  It is inlined -- an out-of-line call would have to
+// save tile registers whose hand-issued loads are still in flight -- and works on the caller's register tile one item
+// pair at a time: recompute the pair's two distances, and only when a lane of the wave survives reserve ring slots for
+// that pair and append.  Nothing but wave-uniform scalars lives across pairs, so the path needs no VGPRs beyond the
+// hot loop's own temporaries (an earlier version that kept all 2*U distances across ONE reservation spilled in the
+// chunk loop; one that re-read the items from memory paid 2*U loaded-HBM round trips per entry).
+struct VcScanRare {
+  uint64_t n;
+  uint32_t* tau;
+  uint32_t* count;
+  uint32_t* hist;
+  uint64_t* buf;
+  const uint64_t* limit;
+  uint32_t id_base, k, cap, hist_stride;
+};
+
 template <int W, int U, int BLK>
-__device__ __forceinline__ void vc_scan_slow(const VcScanParams& p, const vc_u64x2 (&r)[U][W], const uint64_t (&qw)[W],
+__device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2 (&r)[U][W], const uint64_t (&qw)[W],
                                              uint32_t q, uint64_t chunk_base, uint32_t* st) {
   const uint32_t lane = vc_lane();
   uint32_t t = vc_ld_relaxed(p.tau + q);
-  uint32_t dist[2 * U];
-  uint32_t cnt = 0;
+  const uint64_t lim = p.limit ? p.limit[q] : VC_PACK_INF;   // recovery pass: exact packed bound (ties cannot refill the ring)
+  uint64_t* ring = p.buf + (uint64_t)q * p.cap;
+  uint32_t* hist = p.hist + (uint64_t)q * p.hist_stride;
+  uint32_t seen = 0;   // ring fill after this wave's last append (wave-uniform)
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     uint64_t a[W], b[W];
@@ -253,39 +279,29 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanParams& p, const vc_u64
     }
     const uint64_t ia = chunk_base + (uint64_t)u * 2 * BLK + 2 * threadIdx.x;
     const uint32_t da = vc_dist<W>(a, qw), db = vc_dist<W>(b, qw);
-    bool oka = da <= t && ia < p.n, okb = db <= t && ia + 1 < p.n;
-    if (p.limit) {  // recovery pass: exact packed bound, so a flood of ties at the k-th distance cannot refill the ring
-      const uint64_t lim = p.limit[q];
-      oka = oka && vc_pack(da, p.id_base + (uint32_t)ia) <= lim;
-      okb = okb && vc_pack(db, p.id_base + (uint32_t)ia + 1) <= lim;
-    }
-    dist[2 * u] = oka ? da : 0xFFFFFFFFu;
-    dist[2 * u + 1] = okb ? db : 0xFFFFFFFFu;
-    cnt += (dist[2 * u] != 0xFFFFFFFFu) + (dist[2 * u + 1] != 0xFFFFFFFFu);
-  }
-  if (__ballot(cnt != 0) == 0) {  // tau had already moved below everything this wave holds
-    if (lane == 0) st[q] = t;
-    return;
-  }
-  uint32_t total;
-  uint32_t slot = vc_wave_excl_scan(cnt, total);
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(p.count + q, total);
-  base = __builtin_amdgcn_readfirstlane(base);
-  slot += base;
-  uint64_t* ring = p.buf + (uint64_t)q * p.cap;
-  uint32_t* hist = p.hist + (uint64_t)q * p.hist_stride;
-#pragma unroll
-  for (int e = 0; e < 2 * U; ++e) {
-    if (dist[e] != 0xFFFFFFFFu) {
-      const uint64_t id = chunk_base + (uint64_t)(e >> 1) * 2 * BLK + 2 * threadIdx.x + (e & 1);
-      if (slot < p.cap) ring[slot] = vc_pack(dist[e], p.id_base + (uint32_t)id);
+    const uint64_t pa = vc_pack(da, p.id_base + (uint32_t)ia), pb = vc_pack(db, p.id_base + (uint32_t)ia + 1);
+    const bool oka = da <= t && ia < p.n && pa <= lim, okb = db <= t && ia + 1 < p.n && pb <= lim;
+    const uint32_t cnt = (uint32_t)oka + (uint32_t)okb;
+    if (__ballot(cnt != 0) == 0) continue;
+    uint32_t total;
+    uint32_t slot = vc_wave_excl_scan(cnt, total);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(p.count + q, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    slot += base;
+    seen = base + total;
+    if (oka) {
+      if (slot < p.cap) ring[slot] = pa;
       ++slot;
-      atomicAdd(hist + dist[e], 1u);
+      atomicAdd(hist + da, 1u);
+    }
+    if (okb) {
+      if (slot < p.cap) ring[slot] = pb;
+      atomicAdd(hist + db, 1u);
     }
   }
   // re-derive the chip-wide threshold from the histogram of everything appended so far
-  if (base + total >= p.k) {
+  if (seen >= p.k) {
     const uint32_t cut = vc_hist_cut(hist, t + 1, p.k, true);
     if (cut < t) {
       t = cut;
@@ -295,9 +311,19 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanParams& p, const vc_u64
   if (lane == 0) st[q] = t;
 }
 
-// second launch bound = waves per SIMD the register allocation must leave room for
+// Counted wait for hand-issued tile loads: at most N vector-memory operations younger than the tile may still be in
+// flight.  The tile's registers pass through the asm as read-write operands, so every use is ordered behind the wait.
+template <int N, int U, int W>
+__device__ __forceinline__ void vc_tile_wait(vc_u64x2 (&r)[U][W]) {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63));   // 6-bit counter on gfx9; waiting for fewer is only stricter
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int j = 0; j < W; ++j) asm volatile("" : "+v"(r[u][j]));
+}
+
 template <int W, int U, int BLK, int NB>
-__global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : (NB * U * W > 16 ? 3 : 4))) vc_scan_kernel(const VcScanParams p) {
+__global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : ((W >= 4 || NB * U * W > 16) ? 3 : VC_SCAN_MIN_WAVES))) vc_scan_kernel(const VcScanParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* sq = (uint64_t*)smem;                             // [qt][W]  query tile
   uint32_t* st = (uint32_t*)(smem + (size_t)p.qt * W * 8);    // [qt]     block-local copy of tau
@@ -306,19 +332,34 @@ __global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : (NB * U * W > 16 ? 3 : 
   __syncthreads();
 
   constexpr uint64_t CH = 2ull * BLK * U;
+  const VcScanRare rare{p.n, p.tau, p.count, p.hist, p.buf, p.limit, p.id_base, p.k, p.cap, p.hist_stride};
   vc_u64x2 ra[U][W], rb[NB >= 2 ? U : 1][W], rc[NB >= 3 ? U : 1][W];
 
-  auto load = [&](vc_u64x2(&r)[U][W], uint64_t chunk) {
-#if VC_SCAN_DIAGNOSTICS
-    if (p.wrap) chunk %= p.wrap;   // diagnostic: keep the stream cache-resident to time the VALU side alone
-#endif
-    const uint64_t base = chunk * CH + 2 * threadIdx.x;
+  // Prefetch cursor: the chunk the next load() fetches.  Tile loads are issued by hand (inline asm): the address is a
+  // wave-uniform base (SGPR pair, scalar arithmetic) plus ONE constant 32-bit lane offset, so a chunk's U*W loads
+  // cost no VALU address math and no VGPR address pairs.  Left to itself hipcc builds 64-bit VGPR addresses in the
+  // registers of the tile it is about to load and then has to wait (vmcnt(1)) for the tile still in flight before it
+  // may issue the next one -- which serialises the prefetch exactly when HBM and VALU time are balanced.  The
+  // compiler does not track asm loads, so tile_wait<N>() carries the counted s_waitcnt and ties the tile's registers
+  // to it (no use can be scheduled above it).  vmcnt retires in order, so the compiler's own waits for its (rare
+  // path) loads stay correct -- merely conservative -- with ours interleaved.  Past the block's last chunk the
+  // cursor stays put (re-reading that chunk is an L2 hit) so the number of loads in flight is the same on every path.
+  const uint64_t G = gridDim.x;
+  uint64_t pf = blockIdx.x;
+  const uint32_t lane_off = threadIdx.x * (uint32_t)sizeof(vc_u64x2);
+  auto load = [&](vc_u64x2(&r)[U][W]) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int j = 0; j < W; ++j)
-        r[u][j] = VC_SCAN_LOAD(
-            reinterpret_cast<const vc_u64x2*>(p.cols + (uint64_t)j * p.stride + base + (uint64_t)u * 2 * BLK));
+      for (int j = 0; j < W; ++j) {
+        const uint64_t* sbase = p.cols + (uint64_t)j * p.stride + pf * CH + (uint64_t)u * 2 * BLK;
+#if VC_SCAN_NT
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(r[u][j]) : "v"(lane_off), "s"(sbase));
+#else
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r[u][j]) : "v"(lane_off), "s"(sbase));
+#endif
+      }
+    pf += pf + G < p.nchunks ? G : 0;
   };
 
   // one query against the register-resident code tile: xor + accumulating v_bcnt per 32-bit word, running min
@@ -346,7 +387,7 @@ __global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : (NB * U * W > 16 ? 3 : 
       }
       dmin = min(dmin, min(da, db));
     }
-    if (__ballot(dmin <= t) != 0) vc_scan_slow<W, U, BLK>(p, r, qw, q, chunk * CH, st);
+    if (__ballot(dmin <= t) != 0) vc_scan_slow<W, U, BLK>(rare, r, qw, q, chunk * CH, st);
   };
 
   // The query stream is software-pipelined through two register sets: the ds_reads (wave-uniform address =
@@ -357,6 +398,7 @@ __global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : (NB * U * W > 16 ? 3 : 
     t = st[q];
   };
   auto verify = [&](const vc_u64x2(&r)[U][W], uint64_t chunk) {
+#if VC_SCAN_QUERY_PREFETCH
     uint64_t qa[W], qb[W];
     uint32_t ta, tb;
     const uint32_t last = p.qt - 1;
@@ -367,43 +409,53 @@ __global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : (NB * U * W > 16 ? 3 : 
       ldq(qa, ta, min(q + 2, last));
       if (q + 1 < p.qt) one_query(r, qb, tb, q + 1, chunk);
     }
+#else
+    for (uint32_t q = 0; q < p.qt; ++q) {   // the other waves of the SIMD cover the LDS latency; saves 2*W+2 VGPRs
+      uint64_t qa[W];
+      uint32_t ta;
+      ldq(qa, ta, q);
+      one_query(r, qa, ta, q, chunk);
+    }
+#endif
   };
 
   uint64_t chunk = blockIdx.x;
   if (chunk >= p.nchunks) return;
-  const uint64_t G = gridDim.x;
-  // chunk to prefetch `ahead` grid strides from `c`; past the end re-read the current chunk (an L2 hit) so the
-  // number of loads in flight is the same on every path and the compiler can wait with a counted vmcnt for the
-  // buffer being verified while the other buffers' loads stay outstanding.
-  auto ahead = [&](uint64_t c, uint64_t k) { return c + k * G < p.nchunks ? c + k * G : c; };
+  constexpr int T = U * W;  // loads per tile
   if constexpr (NB == 1) {
     // single register buffer: memory latency is covered by the other waves of the SIMD (more of them fit)
     for (; chunk < p.nchunks; chunk += G) {
-      load(ra, chunk);
+      load(ra);
+      vc_tile_wait<0>(ra);
       verify(ra, chunk);
     }
   } else if constexpr (NB == 2) {
-    load(ra, chunk);
+    load(ra);
     for (;;) {
-      load(rb, ahead(chunk, 1));
+      load(rb);
+      vc_tile_wait<T>(ra);
       verify(ra, chunk);
       if ((chunk += G) >= p.nchunks) break;
-      load(ra, ahead(chunk, 1));
+      load(ra);
+      vc_tile_wait<T>(rb);
       verify(rb, chunk);
       if ((chunk += G) >= p.nchunks) break;
     }
   } else {
     // three buffers: two chunks in flight behind the one being verified (absorbs HBM latency jitter)
-    load(ra, chunk);
-    load(rb, ahead(chunk, 1));
+    load(ra);
+    load(rb);
     for (;;) {
-      load(rc, ahead(chunk, 2));
+      load(rc);
+      vc_tile_wait<2 * T>(ra);
       verify(ra, chunk);
       if ((chunk += G) >= p.nchunks) break;
-      load(ra, ahead(chunk, 2));
+      load(ra);
+      vc_tile_wait<2 * T>(rb);
       verify(rb, chunk);
       if ((chunk += G) >= p.nchunks) break;
-      load(rb, ahead(chunk, 2));
+      load(rb);
+      vc_tile_wait<2 * T>(rc);
       verify(rc, chunk);
       if ((chunk += G) >= p.nchunks) break;
     }

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libverticut_gpu.so")
+LIB_PATH = os.environ.get("VERTICUT_GPU_LIB") or os.path.join(_HERE, "lib", "libverticut_gpu.so")   # env: A/B builds
 
 VC_ABI_VERSION = 1
 VC_OK, VC_NOT_FOUND = 0, 1
