@@ -33,6 +33,10 @@
 #ifndef VC_SCAN_QUERY_PREFETCH
 #define VC_SCAN_QUERY_PREFETCH 1
 #endif
+// ring-fill stride at which the chip-wide threshold is re-derived from the histogram
+#ifndef VC_SCAN_RECUT_EVERY
+#define VC_SCAN_RECUT_EVERY 32u
+#endif
 #if VC_SCAN_NT
 #define VC_SCAN_LOAD(ptr) __builtin_nontemporal_load(ptr)
 #else
@@ -269,6 +273,7 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
   uint64_t* ring = p.buf + (uint64_t)q * p.cap;
   uint32_t* hist = p.hist + (uint64_t)q * p.hist_stride;
   uint32_t seen = 0;   // ring fill after this wave's last append (wave-uniform)
+  bool recut = false;  // an append of this wave crossed a VC_SCAN_RECUT_EVERY boundary of the ring fill
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     uint64_t a[W], b[W];
@@ -290,6 +295,7 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
     base = __builtin_amdgcn_readfirstlane(base);
     slot += base;
     seen = base + total;
+    recut = recut || (base / VC_SCAN_RECUT_EVERY != seen / VC_SCAN_RECUT_EVERY) || (base < p.k && seen >= p.k);
     if (oka) {
       if (slot < p.cap) ring[slot] = pa;
       ++slot;
@@ -300,8 +306,10 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
       atomicAdd(hist + db, 1u);
     }
   }
-  // re-derive the chip-wide threshold from the histogram of everything appended so far
-  if (seen >= p.k) {
+  // re-derive the chip-wide threshold from the histogram of everything appended so far -- not on every entry: the
+  // histogram lines are read coherently by every wave that gets here, and same-line coherent accesses serialise in
+  // L2 (~27 ns each), so only the wave whose append crosses a multiple of VC_SCAN_RECUT_EVERY entries does it
+  if (seen >= p.k && recut) {
     const uint32_t cut = vc_hist_cut(hist, t + 1, p.k, true);
     if (cut < t) {
       t = cut;
