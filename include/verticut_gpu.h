@@ -57,6 +57,10 @@ extern "C" {
                                           even when n_tables < 4.  Default: min(n_tables,4), identical to the
                                           reference whenever the reference itself is exact. */
 
+#define VC_FLAG_LEAN_TIMING 0x8u       /* time only the verify-kernel launches (vc_timing.scan_*): no event pair around each
+                                          search call, so vc_timing.total_ms / calls stay 0.  Each event record is a barrier
+                                          packet in the stream (~4 us); a throughput loop that keeps its own clock sets this. */
+
 /* ---- synthetic data kinds for vc_add_synthetic (the reference ships no data: .gitignore:7-8) */
 #define VC_SYNTH_UNIFORM 0
 #define VC_SYNTH_CLUSTERED 1

@@ -1,10 +1,6 @@
 timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for rep in 1 2; do
-for v in R1 R8 R32 R128; do
-if [ $v = R32 ]; then unset VERTICUT_GPU_LIB; else export VERTICUT_GPU_LIB=$PWD/verticut_amd/lib/ab/lib$v.so; fi
-echo "== $v 125M"; timeout -k 10 300 python tools/sweep_scan.py 1.25e8 128 1,8,16 0
-done; done
-for v in R1 R32 R128; do
-if [ $v = R32 ]; then unset VERTICUT_GPU_LIB; else export VERTICUT_GPU_LIB=$PWD/verticut_amd/lib/ab/lib$v.so; fi
-echo "== $v 1e9"; timeout -k 10 300 python tools/sweep_scan.py 1e9 128 1,6,8,10,16 0
-done
+run() { python bench.py --db-size $1 --steps 40 --warmup 10 --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('  qps %.0f  step %.4f ms  scan %.4f ms' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms']))"; }
+for r in 1 2 3; do echo "== 125M"; run 125000000; done
+for r in 1 2; do echo "== 1e9"; run 1000000000; done
+echo "== forced exchange 125M"; VC_BENCH_FORCE_EXCHANGE=1 python bench.py --db-size 125000000 --steps 40 --warmup 10 --cpu-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('  qps %.0f  step %.4f ms' % (d['value'], d['ms_per_step']))"
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/tl125c -- python $GRAFT_REPO_ROOT/bench.py --db-size 125000000 --steps 30 --warmup 5 --cpu-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/tl125c.log 2>&1; cd $GRAFT_REPO_ROOT && python tools/step_timeline.py $(ls gpurun_out/tl125c/*/*_kernel_trace.csv) 1

@@ -35,8 +35,12 @@ struct vc_engine {
   size_t ev_used = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_calls, ev_scans;
   hipEvent_t cur_t0 = nullptr;
-  hipEvent_t last_call = nullptr;   // end of the most recent search call: the next call (any stream) waits for it,
-  bool last_call_valid = false;     // because all calls share the engine's work buffers
+  // All search calls share the engine's work buffers, so a call must run after the previous one.  On the same stream
+  // that is stream order; when the stream changes, the new call records an event at the tail of the previous stream
+  // and waits for it (lazily: the common same-stream loop pays no event at all).
+  hipEvent_t last_call = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool last_stream_valid = false;
   uint64_t scan_bytes = 0;
   vc_timing last{};
 
@@ -330,13 +334,22 @@ static int ev_pair(vc_engine* e, hipEvent_t* a, hipEvent_t* b) {
   return VC_OK;
 }
 static void timing_begin(vc_engine* e) {
-  if (e->last_call_valid) (void)hipStreamWaitEvent(e->stream, e->last_call, 0);
-  e->cur_t0 = ev_take(e);
+  if (e->last_stream_valid && e->last_stream != e->stream) {
+    if (!e->last_call && hipEventCreateWithFlags(&e->last_call, hipEventDisableTiming) != hipSuccess) e->last_call = nullptr;
+    // the previous stream may be gone by now (the caller's to destroy): then everything it held has been submitted
+    // and a device-wide wait is the safe fallback
+    if (!e->last_call || hipEventRecord(e->last_call, e->last_stream) != hipSuccess ||
+        hipStreamWaitEvent(e->stream, e->last_call, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+    }
+  }
+  e->cur_t0 = (e->cfg.flags & VC_FLAG_LEAN_TIMING) ? nullptr : ev_take(e);
   if (e->cur_t0) (void)hipEventRecord(e->cur_t0, e->stream);
 }
 static void timing_end(vc_engine* e) {
-  if (!e->last_call && hipEventCreateWithFlags(&e->last_call, hipEventDisableTiming) != hipSuccess) e->last_call = nullptr;
-  if (e->last_call) e->last_call_valid = hipEventRecord(e->last_call, e->stream) == hipSuccess;
+  e->last_stream = e->stream;
+  e->last_stream_valid = true;
   if (!e->cur_t0) return;
   hipEvent_t t1 = ev_take(e);
   if (!t1) { --e->ev_used; e->cur_t0 = nullptr; return; }

@@ -753,7 +753,9 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
   }
   const uint32_t gy = (qt + VC_SAMPLE_QSUB - 1) / VC_SAMPLE_QSUB;
   const uint64_t npairs = std::max<uint64_t>((s_items + 1) / 2, 1);
-  const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * 8);
+  uint64_t per_cu = 4;   // more blocks = more same-address atomics in the flush (measured 4 < 8 on a 125 M-code shard)
+  if (const char* g = getenv("VC_SAMPLE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(g));   // dev knob
+  const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * per_cu);
   const size_t lds = (size_t)VC_SAMPLE_QSUB * W * 8 + (size_t)VC_SAMPLE_QSUB * hist_stride * 4 + VC_SAMPLE_QSUB * 4;
   VcSampleParams p{cols, stride, s_items, d_queries, d_shist, d_tau, qt, hist_stride, refine ? 1u : 0u};
 #define VC_SH_CASE(W_)                                                                                   \

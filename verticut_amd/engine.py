@@ -15,7 +15,7 @@ VC_ABI_VERSION = 1
 VC_OK, VC_NOT_FOUND = 0, 1
 VC_ERR_INVALID, VC_ERR_NO_DEVICE, VC_ERR_HIP, VC_ERR_NOMEM, VC_ERR_STATE, VC_ERR_CAPACITY = -1, -2, -3, -4, -5, -6
 MODE_LINEAR, MODE_MIH_EXACT, MODE_MIH_APPROX = 0, 1, 2
-FLAG_USE_BITMAP, FLAG_REF_SIGNEXT_KEYS, FLAG_REF_STOP_LITERAL4 = 1, 2, 4
+FLAG_USE_BITMAP, FLAG_REF_SIGNEXT_KEYS, FLAG_REF_STOP_LITERAL4, FLAG_LEAN_TIMING = 1, 2, 4, 8
 SYNTH_UNIFORM, SYNTH_CLUSTERED = 0, 1
 ORDER_ASCENDING, ORDER_FARTHEST_FIRST = 0, 1
 PACK_INF = np.uint64(0xFFFFFFFFFFFFFFFF)

@@ -23,6 +23,8 @@ class GpuBackend:
     """Local shard search + merge through libverticut_gpu.so."""
 
     def __init__(self, bits, capacity, id_base, n_tables=0, device=0, **kw):
+        # the serving loop keeps its own clock: only the verify-kernel launches are bracketed by events
+        kw["flags"] = kw.get("flags", 0) | vc.FLAG_LEAN_TIMING
         self.engine = vc.Engine(bits, capacity=max(capacity, 1), n_tables=n_tables, id_base=id_base, device=device, **kw)
         self.device = torch.device("cuda", device)
 
