@@ -15,6 +15,7 @@
 #define VC_PAD_ITEMS 8192ull     // column stride granularity: every scan chunk shape divides this
 #define VC_MAX_W 8               // 512-bit codes
 #define VC_PACK_INF 0xFFFFFFFFFFFFFFFFull
+#define VC_SHIST_COPIES 16       // partial histograms per bootstrap stage (spreads the flush atomics over L2 channels)
 
 // native 16-byte vector (two uint64): one global_load_dwordx4 per lane
 typedef unsigned long long vc_u64x2 __attribute__((ext_vector_type(2)));

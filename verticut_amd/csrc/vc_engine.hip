@@ -401,15 +401,15 @@ static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
   b->hs = (e->bits + 1 + 7) & ~7u;
   b->QT = std::min(e->qtile, nq);
   b->cap = std::max(e->cap, 4 * k);
-  b->state_words = (size_t)b->QT * (1 + 3 * (size_t)b->hs + 1);
+  b->state_words = (size_t)b->QT * (1 + (1 + 2 * (size_t)VC_SHIST_COPIES) * (size_t)b->hs + 1);
   int rc;
   if ((rc = grow(e, &e->d_state, &e->state_bytes, b->state_words * 4))) return rc;
   if ((rc = grow(e, &e->d_ring, &e->ring_bytes, (size_t)b->QT * b->cap * 8))) return rc;
   b->d_count = e->d_state;
   b->d_hist = b->d_count + b->QT;
   b->d_shist = b->d_hist + (size_t)b->QT * b->hs;
-  b->d_shist2 = b->d_shist + (size_t)b->QT * b->hs;
-  b->d_tau = b->d_shist2 + (size_t)b->QT * b->hs;
+  b->d_shist2 = b->d_shist + (size_t)VC_SHIST_COPIES * b->QT * b->hs;
+  b->d_tau = b->d_shist2 + (size_t)VC_SHIST_COPIES * b->QT * b->hs;
   return VC_OK;
 }
 

@@ -133,13 +133,21 @@ __device__ __forceinline__ uint32_t vc_dist(const uint64_t (&c)[W], const uint64
 #define VC_SAMPLE_QSUB 32
 
 // smallest d with  sum_{d' <= d} h[d'] >= k  (0xFFFFFFFF if the histogram holds fewer than k).  One wave.
-__device__ __forceinline__ uint32_t vc_hist_cut(const uint32_t* h, uint32_t nbins, uint32_t k, bool atomic_reads) {
+// The histogram may be split into `copies` partial histograms `cstride` words apart (the bootstrap kernels flush into
+// several copies so that their same-address atomics spread over L2 channels); a bin's count is the sum over copies.
+__device__ __forceinline__ uint32_t vc_hist_cut(const uint32_t* h, uint32_t nbins, uint32_t k, bool atomic_reads,
+                                                uint32_t copies = 1, uint64_t cstride = 0) {
   const uint32_t lane = vc_lane();
   const uint32_t bpl = (nbins + VC_WAVE - 1) / VC_WAVE;  // consecutive bins per lane
+  auto bin_count = [&](uint32_t bin) {
+    uint32_t c = 0;
+    for (uint32_t r = 0; r < copies; ++r) c += atomic_reads ? vc_ld_relaxed(h + r * cstride + bin) : h[r * cstride + bin];
+    return c;
+  };
   uint32_t mine = 0;
   for (uint32_t i = 0; i < bpl; ++i) {
     const uint32_t bin = lane * bpl + i;
-    if (bin < nbins) mine += atomic_reads ? vc_ld_relaxed(h + bin) : h[bin];
+    if (bin < nbins) mine += bin_count(bin);
   }
   uint32_t total;
   uint32_t run = vc_wave_excl_scan(mine, total);
@@ -147,7 +155,7 @@ __device__ __forceinline__ uint32_t vc_hist_cut(const uint32_t* h, uint32_t nbin
   for (uint32_t i = 0; i < bpl; ++i) {
     const uint32_t bin = lane * bpl + i;
     if (bin < nbins) {
-      run += atomic_reads ? vc_ld_relaxed(h + bin) : h[bin];
+      run += bin_count(bin);
       if (run >= k && cand == 0xFFFFFFFFu) cand = bin;
     }
   }
@@ -159,7 +167,7 @@ struct VcSampleParams {
   uint64_t stride;
   uint64_t s_items;          // histogram the first s_items codes
   const uint64_t* queries;   // [qt][W]
-  uint32_t* shist;           // [qt][hs] zeroed by the caller
+  uint32_t* shist;           // [VC_SHIST_COPIES][qt][hs] zeroed by the caller; block b flushes into copy b % COPIES
   const uint32_t* tau;       // [qt] refine: only distances <= tau[q] are counted
   uint32_t qt, hs, refine;
 };
@@ -182,40 +190,40 @@ __global__ void __launch_bounds__(256) vc_sample_hist_kernel(const VcSampleParam
 
   const uint64_t npairs = (p.s_items + 1) / 2;
   const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-  constexpr int NP = 1;   // item pairs per lane per round (more pairs cost occupancy: measured slower at 2 and 4)
-  for (uint64_t pr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; pr < npairs; pr += NP * step) {
-    uint64_t it[2 * NP][W];
-    bool ok[2 * NP];
+  // one item pair per lane per round, the next round's pair already in flight (register double buffer)
+  auto fetch = [&](vc_u64x2(&v)[W], uint64_t pr) {
+    const uint64_t pc = pr < npairs ? pr : npairs - 1;   // clamp: the duplicate is never counted
 #pragma unroll
-    for (int g = 0; g < NP; ++g) {
-      const uint64_t pg = pr + g * step;
-      const bool in = pg < npairs;
-      const uint64_t pc = in ? pg : pr;              // clamp: the duplicate is masked out below
+    for (int j = 0; j < W; ++j) v[j] = *reinterpret_cast<const vc_u64x2*>(p.cols + j * p.stride + 2 * pc);
+  };
+  uint64_t pr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  vc_u64x2 cur[W], nxt[W];
+  if (pr < npairs) fetch(cur, pr);
+  for (; pr < npairs; pr += step) {
+    fetch(nxt, pr + step);
+    uint64_t a[W], b[W];
 #pragma unroll
-      for (int j = 0; j < W; ++j) {
-        const vc_u64x2 v = *reinterpret_cast<const vc_u64x2*>(p.cols + j * p.stride + 2 * pc);
-        it[2 * g][j] = v.x;
-        it[2 * g + 1][j] = v.y;
-      }
-      ok[2 * g] = in;
-      ok[2 * g + 1] = in && (2 * pc + 1) < p.s_items;
+    for (int j = 0; j < W; ++j) {
+      a[j] = cur[j].x;
+      b[j] = cur[j].y;
     }
+    const bool okb = 2 * pr + 1 < p.s_items;
     for (uint32_t q = 0; q < nq; ++q) {
       uint64_t qw[W];
 #pragma unroll
       for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
       const uint32_t t = sthr[q];
-#pragma unroll
-      for (int i = 0; i < 2 * NP; ++i) {
-        const uint32_t d = vc_dist<W>(it[i], qw);
-        if (ok[i] && d <= t) atomicAdd(&lh[q * hs + d], 1u);
-      }
+      const uint32_t da = vc_dist<W>(a, qw), db = vc_dist<W>(b, qw);
+      if (da <= t) atomicAdd(&lh[q * hs + da], 1u);
+      if (okb && db <= t) atomicAdd(&lh[q * hs + db], 1u);
     }
+#pragma unroll
+    for (int j = 0; j < W; ++j) cur[j] = nxt[j];
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < nq * hs; i += blockDim.x) {
     const uint32_t c = lh[i];
-    if (c) atomicAdd(&p.shist[(uint64_t)q0 * hs + i], c);
+    if (c) atomicAdd(&p.shist[(uint64_t)(blockIdx.x % VC_SHIST_COPIES) * p.qt * hs + (uint64_t)q0 * hs + i], c);
   }
 }
 
@@ -225,7 +233,7 @@ __global__ void __launch_bounds__(256) vc_sample_hist_kernel(const VcSampleParam
 __global__ void __launch_bounds__(64) vc_tau_init_kernel(const uint32_t* __restrict__ shist, uint32_t hs, uint32_t k,
                                                          uint32_t bits, uint32_t* __restrict__ tau, uint32_t refine) {
   const uint32_t q = blockIdx.x;
-  const uint32_t cut = vc_hist_cut(shist + (uint64_t)q * hs, bits + 1, k, false);
+  const uint32_t cut = vc_hist_cut(shist + (uint64_t)q * hs, bits + 1, k, false, VC_SHIST_COPIES, (uint64_t)gridDim.x * hs);
   if (threadIdx.x == 0) tau[q] = (cut == 0xFFFFFFFFu) ? (refine ? tau[q] : bits) : (refine ? min(cut, tau[q]) : cut);
 }
 
@@ -753,7 +761,7 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
   }
   const uint32_t gy = (qt + VC_SAMPLE_QSUB - 1) / VC_SAMPLE_QSUB;
   const uint64_t npairs = std::max<uint64_t>((s_items + 1) / 2, 1);
-  uint64_t per_cu = 4;   // more blocks = more same-address atomics in the flush (measured 4 < 8 on a 125 M-code shard)
+  uint64_t per_cu = 8;
   if (const char* g = getenv("VC_SAMPLE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(g));   // dev knob
   const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * per_cu);
   const size_t lds = (size_t)VC_SAMPLE_QSUB * W * 8 + (size_t)VC_SAMPLE_QSUB * hist_stride * 4 + VC_SAMPLE_QSUB * 4;
