@@ -123,8 +123,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": device} if backend == "nccl" else {}))
+    engine_kw = {}
+    if os.environ.get("VC_BENCH_SCAN_BLOCKS"):      # dev: cap the persistent verify grid (leave block slots to other kernels)
+        engine_kw["scan_blocks"] = int(os.environ["VC_BENCH_SCAN_BLOCKS"])
     ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=local_rank, query_tile=Q,
-                       force_exchange=force_exchange)
+                       force_exchange=force_exchange, **engine_kw)
     ss.add_synthetic(args.seed)
 
     # query batches resident in HBM: uniform random codes = worst case (no early threshold help)
