@@ -139,6 +139,15 @@ def test_device_api_matches_host_api(vc, oracle):
         assert np.array_equal(out.cpu().numpy().view(np.uint64), host) and np.array_equal(cnt.cpu().numpy(), hcnt)
         t = e.timing()
         assert t.calls == 2 and t.scan_launches == 2
+    # VC_FLAG_LEAN_TIMING: same results, only the verify launches are bracketed by events
+    with vc.Engine(bits, capacity=n, flags=vc.FLAG_LEAN_TIMING) as e:
+        e.add_synthetic(n, seed=6)
+        lean, lcnt = e.search_knn(q, k)
+        e.search_knn_dev(dq.data_ptr(), 9, k, out.data_ptr(), cnt.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        assert np.array_equal(lean, host) and np.array_equal(out.cpu().numpy().view(np.uint64), host)
+        t = e.timing()
+        assert t.calls == 0 and t.total_ms == 0 and t.scan_launches == 2 and t.scan_ms > 0
 
 
 def test_device_api_is_ordered_on_the_callers_stream(vc):

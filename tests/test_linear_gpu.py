@@ -127,6 +127,22 @@ def test_ring_overflow_recovery(vc, oracle):
         assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp)
 
 
+def test_ring_overflow_with_tiny_ring_and_loose_early_entries(vc, oracle):
+    """k = 1, ring of 4: the entries that fit arrive under the loose start threshold while thousands of duplicates
+    (counted in the histogram, not stored) pull the final threshold below all of them -- the recovery bound must
+    still come from what fitted (regression: the select pre-filter used to empty such a row)."""
+    n = 400_000
+    codes = oracle.gen_codes(n, 256, 900, kind=1, n_centres=7, max_flips=0)    # 7 distinct codes, ~57 K copies each
+    q = codes[[3, 1000, 77777, 399_999]].copy()
+    q[1, 0] ^= 1
+    with vc.Engine(256, capacity=n, query_tile=4, cand_cap=4) as e:
+        e.add_codes(codes)
+        for k in (1, 3):
+            got, cnt = e.search_knn(q, k)
+            exp, ecnt = _expect(oracle, codes, q, k)
+            assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp)
+
+
 def test_timing_reports_scan(vc):
     with vc.Engine(128, capacity=1 << 20) as e:
         e.add_synthetic(1 << 20, seed=1)

@@ -479,8 +479,16 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
 }
 
 // Ring-overflow recovery (host-driven, rare: more than `cap` items at or below the k-th distance).  The truncated
-// ring still yields a valid upper bound L on the k-th best packed value; the query is scanned again appending only
-// packed values <= L.  Every round at least quarters the survivors' bound (cap >= 4k distinct values <= L), so it ends.
+// ring still yields a valid upper bound on the k-th best packed value (the k-th best of what fitted); the query is
+// scanned again appending only packed values <= a probe, and the append counter tells EXACTLY how many items lie at
+// or below the probe whether they fitted or not.  Per query an interval (lo, hi] is kept with count(<= lo) < k <=
+// count(<= hi):
+//   * probe = hi; the k-th best of what fitted becomes the new hi.  With entries arriving in random order that
+//     quarters the survivors per round (cap >= 4k); but arrival order is NOT random (the same early waves deliver
+//     ids just under the limit round after round: tools/parity_campaign.py case 259 needed > 64 rounds), so
+//   * whenever a round fails to halve the survivors the next probe bisects (lo, hi] instead: fewer than k items
+//     below it -> lo = probe; otherwise hi = min(probe, k-th best of what fitted).
+// Each bisection halves a 64-bit interval, the other steps never widen it: it ends.
 static int linear_recover(vc_engine* e, const uint64_t* d_q, uint32_t k, const std::vector<uint32_t>& over,
                           uint64_t* out /*host [nq][k]*/, uint32_t* cnt /*host [nq]*/) {
   LinearBufs b;
@@ -494,19 +502,33 @@ static int linear_recover(vc_engine* e, const uint64_t* d_q, uint32_t k, const s
   RC(hipMalloc((void**)&d_rq, b.QT * W * 8));
   RC(hipMalloc((void**)&d_lim, b.QT * 8));
   RC(hipMalloc((void**)&d_rout, (size_t)b.QT * k * 8));
-  RC(hipMalloc((void**)&d_rcnt, b.QT * 8));
-  std::vector<uint32_t> todo = over;
+  RC(hipMalloc((void**)&d_rcnt, b.QT * 4));
+  struct Rec {
+    uint32_t q;          // query index in the caller's batch
+    uint64_t lo, hi;     // count(<= lo) < k (valid only if has_lo), count(<= hi) >= k
+    bool has_lo;
+    uint64_t prev;       // survivors of the previous round (0 = none yet)
+    bool bisect;         // this round's probe is the midpoint, not hi
+    uint64_t probe;
+  };
+  std::vector<Rec> todo;
+  for (uint32_t q : over) todo.push_back(Rec{q, 0, out[(size_t)q * k + k - 1], false, 0, false, 0});
+  const bool trace = getenv("VC_RECOVER_TRACE") != nullptr;   // dev knob
   for (int round = 0; !todo.empty(); ++round) {
-    if (round > 64) { cleanup(); return fail(e, VC_ERR_CAPACITY, "ring overflow recovery did not converge"); }
-    std::vector<uint32_t> next;
+    if (round > 200) { cleanup(); return fail(e, VC_ERR_CAPACITY, "ring overflow recovery did not converge"); }
+    std::vector<Rec> next;
     for (size_t t0 = 0; t0 < todo.size(); t0 += b.QT) {
       const uint32_t qt = (uint32_t)std::min<size_t>(b.QT, todo.size() - t0);
       std::vector<uint64_t> lim(qt);
       std::vector<uint32_t> tau(qt);
       for (uint32_t i = 0; i < qt; ++i) {
-        const uint32_t q = todo[t0 + i];
-        RC(hipMemcpyAsync(d_rq + i * W, d_q + (size_t)q * W, W * 8, hipMemcpyDeviceToDevice, e->stream));
-        lim[i] = out[(size_t)q * k + k - 1];          // k-th best of what fitted: >= the true k-th best
+        Rec& r = todo[t0 + i];
+        RC(hipMemcpyAsync(d_rq + i * W, d_q + (size_t)r.q * W, W * 8, hipMemcpyDeviceToDevice, e->stream));
+        if (!r.bisect) r.probe = r.hi;
+        else if (r.has_lo) r.probe = r.lo + (r.hi - r.lo + 1) / 2;   // rounds up: lo < probe <= hi, so the interval always shrinks
+        else if (r.hi >> 32) r.probe = ((r.hi >> 32) << 32) - 1;   // first: everything strictly nearer than hi's distance
+        else r.probe = r.hi / 2;
+        lim[i] = r.probe;
         tau[i] = (uint32_t)(lim[i] >> 32);
       }
       RC(hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
@@ -521,10 +543,27 @@ static int linear_recover(vc_engine* e, const uint64_t* d_q, uint32_t k, const s
       RC(hipMemcpyAsync(raw.data(), b.d_count, qt * 4, hipMemcpyDeviceToHost, e->stream));
       RC(hipStreamSynchronize(e->stream));
       for (uint32_t i = 0; i < qt; ++i) {
-        const uint32_t q = todo[t0 + i];
-        memcpy(out + (size_t)q * k, rout.data() + (size_t)i * k, (size_t)k * 8);
-        cnt[q] = rcnt[i];
-        if (raw[i] > b.cap) next.push_back(q);
+        Rec r = todo[t0 + i];
+        const uint64_t c = raw[i];                     // exact number of items <= probe
+        const uint64_t want = std::min<uint64_t>(k, e->n);
+        if (trace && i == 0)
+          fprintf(stderr, "[vc recover] round %d query %u: %s probe %016llx -> %llu items (cap %u)\n", round, r.q,
+                  r.bisect ? "bisect" : "bound ", (unsigned long long)r.probe, (unsigned long long)c, b.cap);
+        if (c < want) {                                // only a bisection probe can undershoot
+          r.lo = r.probe;
+          r.has_lo = true;
+          r.bisect = true;
+          next.push_back(r);
+          continue;
+        }
+        // a valid row: everything <= probe was counted, the best min(c, cap) >= k of it was stored
+        memcpy(out + (size_t)r.q * k, rout.data() + (size_t)i * k, (size_t)k * 8);
+        cnt[r.q] = rcnt[i];
+        if (c <= b.cap) continue;                      // nothing was dropped: exact, done
+        r.hi = std::min(r.probe, rout[(size_t)i * k + k - 1]);
+        r.bisect = r.prev != 0 && c * 2 > r.prev;      // poor progress since the last valid round -> bisect next
+        r.prev = c;
+        next.push_back(r);
       }
     }
     todo.swap(next);

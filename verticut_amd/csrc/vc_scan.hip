@@ -495,7 +495,13 @@ struct VcRingSrc {
   uint32_t mark_overflow; // report count = UINT32_MAX when the ring overflowed (row is then only an upper bound)
   const uint32_t* tau;    // optional final distance thresholds: entries farther than tau[q] cannot be in the top-k
   __device__ uint32_t slot(uint32_t b) const { return list ? list[b] : b; }
-  __device__ uint64_t bound(uint32_t q) const { return tau ? (((uint64_t)tau[q] + 1) << 32) : VC_PACK_INF; }
+  // Pre-filter by the final threshold -- but not when the ring overflowed: tau comes from the histogram of ALL
+  // survivors, stored or not, so it can lie below every entry that did fit (early arrivals under a loose tau), and
+  // the recovery pass needs the k-th best of what fitted as its bound (found by tools/parity_campaign.py: k = 1,
+  // cap = 4, thousands of duplicates -> empty row -> no bound -> "recovery did not converge").
+  __device__ uint64_t bound(uint32_t q) const {
+    return (tau && count[q] <= cap) ? (((uint64_t)tau[q] + 1) << 32) : VC_PACK_INF;
+  }
   __device__ bool overflowed(uint32_t q) const { return mark_overflow && count[q] > cap; }
   __device__ uint32_t size(uint32_t q) const { return min(count[q], cap); }
   __device__ uint64_t get(uint32_t q, uint32_t i) const { return buf[(uint64_t)q * cap + i]; }
