@@ -37,11 +37,6 @@
 #ifndef VC_SCAN_RECUT_EVERY
 #define VC_SCAN_RECUT_EVERY 32u
 #endif
-#if VC_SCAN_NT
-#define VC_SCAN_LOAD(ptr) __builtin_nontemporal_load(ptr)
-#else
-#define VC_SCAN_LOAD(ptr) (*(ptr))
-#endif
 
 namespace {
 
@@ -368,7 +363,9 @@ __global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : ((W >= 4 || NB * U * W 
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < W; ++j) {
-        const uint64_t* sbase = p.cols + (uint64_t)j * p.stride + pf * CH + (uint64_t)u * 2 * BLK;
+        // (diagnostic build, VC_SCAN_WRAP: the stream wraps onto the first `wrap` chunks = cache resident)
+        const uint64_t c = (VC_SCAN_DIAGNOSTICS && p.wrap) ? pf % p.wrap : pf;
+        const uint64_t* sbase = p.cols + (uint64_t)j * p.stride + c * CH + (uint64_t)u * 2 * BLK;
 #if VC_SCAN_NT
         asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(r[u][j]) : "v"(lane_off), "s"(sbase));
 #else
