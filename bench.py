@@ -144,6 +144,10 @@ def main():
         ss.flush()                  # N > 1, pipelined exchange: the last batches' side-stream work joins this stream
         return res
 
+    # Priming, part of set-up like the data generation above: the first launches after the 16 GB fill run 10-15 %
+    # slow (clocks, page tables; kernel trace in profiles/), and a driver-chosen --warmup may be shorter than that.
+    run_steps(8)
+    torch.cuda.synchronize()
     run_steps(args.warmup)
     torch.cuda.synchronize()
     exchange = "none"

@@ -366,10 +366,14 @@ __global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : ((W >= 4 || NB * U * W 
         // (diagnostic build, VC_SCAN_WRAP: the stream wraps onto the first `wrap` chunks = cache resident)
         const uint64_t c = (VC_SCAN_DIAGNOSTICS && p.wrap) ? pf % p.wrap : pf;
         const uint64_t* sbase = p.cols + (uint64_t)j * p.stride + c * CH + (uint64_t)u * 2 * BLK;
+        // The base goes through an s_mov inside the asm: hipcc cannot see the VMEM instruction in here, so it would
+        // not pad the 5 wait states gfx9 needs between a VALU write of an SGPR (v_readfirstlane, v_cmp) and a VMEM
+        // read of it, should it ever compute the base that way; an SGPR written by the SALU has no such hazard.
+        const uint64_t* sb;
 #if VC_SCAN_NT
-        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(r[u][j]) : "v"(lane_off), "s"(sbase));
+        asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1 nt" : "=&v"(r[u][j]), "=&s"(sb) : "v"(lane_off), "s"(sbase));
 #else
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r[u][j]) : "v"(lane_off), "s"(sbase));
+        asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1" : "=&v"(r[u][j]), "=&s"(sb) : "v"(lane_off), "s"(sbase));
 #endif
       }
     pf += pf + G < p.nchunks ? G : 0;
