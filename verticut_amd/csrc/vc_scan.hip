@@ -271,6 +271,10 @@ template <int W, int U, int BLK>
 __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2 (&r)[U][W], const uint64_t (&qw)[W],
                                              uint32_t q, uint64_t chunk_base, uint32_t* st) {
   const uint32_t lane = vc_lane();
+  // The thread index enters through an opaque statement INSIDE the rare branch: otherwise hipcc hoists the item ids
+  // of all U pairs (invariant across the query loop) to tile level and keeps them alive through the hot loop.
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   uint32_t t = vc_ld_relaxed(p.tau + q);
   const uint64_t lim = p.limit ? p.limit[q] : VC_PACK_INF;   // recovery pass: exact packed bound (ties cannot refill the ring)
   uint64_t* ring = p.buf + (uint64_t)q * p.cap;
@@ -285,7 +289,7 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
       a[j] = r[u][j].x;
       b[j] = r[u][j].y;
     }
-    const uint64_t ia = chunk_base + (uint64_t)u * 2 * BLK + 2 * threadIdx.x;
+    const uint64_t ia = chunk_base + (uint64_t)u * 2 * BLK + 2 * tid;
     const uint32_t da = vc_dist<W>(a, qw), db = vc_dist<W>(b, qw);
     const uint64_t pa = vc_pack(da, p.id_base + (uint32_t)ia), pb = vc_pack(db, p.id_base + (uint32_t)ia + 1);
     const bool oka = da <= t && ia < p.n && pa <= lim, okb = db <= t && ia + 1 < p.n && pb <= lim;
