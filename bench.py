@@ -126,8 +126,11 @@ def main():
     engine_kw = {}
     if os.environ.get("VC_BENCH_SCAN_BLOCKS"):      # dev: cap the persistent verify grid (leave block slots to other kernels)
         engine_kw["scan_blocks"] = int(os.environ["VC_BENCH_SCAN_BLOCKS"])
+    # N > 1: the per-shard top-k of 8 consecutive batches share one all-gather + merge (ShardedSearch(bucket=8)): the
+    # collective is latency-bound at 6.4 KB per rank, every step still ends inside the timed region (flush()).
+    bucket = int(os.environ.get("VC_BENCH_BUCKET", "8")) if (world > 1 or force_exchange) else 1
     ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=local_rank, query_tile=Q,
-                       force_exchange=force_exchange, **engine_kw)
+                       force_exchange=force_exchange, bucket=bucket, **engine_kw)
     ss.add_synthetic(args.seed)
 
     # query batches resident in HBM: uniform random codes = worst case (no early threshold help)
@@ -156,7 +159,7 @@ def main():
         # VC_BENCH_PIPELINED=1 moves it to a side stream under the next batch's scan (ShardedSearch(pipelined=True));
         # that path is covered by tests but has never run over RCCL on a multi-GPU node, so it is opt-in.
         ss.pipelined = os.environ.get("VC_BENCH_PIPELINED") == "1"
-        exchange = "side-stream" if ss.pipelined else "inline"
+        exchange = "side-stream" if ss.pipelined else ("inline, %d batches per all-gather" % bucket if bucket > 1 else "inline")
         if ss.pipelined:
             run_steps(2)
             torch.cuda.synchronize()

@@ -64,6 +64,39 @@ def _worker(rank, world, port, total_n, bits, k, ret):
     dist.destroy_process_group()
 
 
+def _worker_bucketed(rank, world, port, total_n, bits, k, ret):
+    """bucket = 3, five batches: one full bucket exchanged by the third call, a partial one by flush()"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import vc_oracle as vo
+    lo, hi = shard_range(total_n, rank, world)
+    ss = ShardedSearch(bits, total_n, rank=rank, world=world, backend=OracleBackend(vo, bits, lo), bucket=3)
+    ss.add_synthetic(34, kind=1, n_centres=20, max_flips=6)
+    full = vo.gen_codes(total_n, bits, 34, 1, 20, 6)
+    rng = np.random.default_rng(5)
+    ok = True
+    pending = []
+
+    def check_pending():
+        nonlocal ok
+        for q, (out, cnt) in pending:
+            exp = np.stack([vo.linear_knn(full, q[i], k) for i in range(len(q))])
+            ok = ok and np.array_equal(out.numpy().view(np.uint64), exp) and bool(np.all(cnt.numpy() == k))
+        pending.clear()
+
+    for b in range(5):
+        q = full[rng.integers(0, total_n, size=4)].copy()
+        q[:, b] ^= 0x21
+        pending.append((q, ss.search(torch.from_numpy(q), k)))
+        if (b + 1) % 3 == 0:
+            check_pending()          # the third call exchanged the bucket (its buffers are reused by the next bucket)
+    ss.flush()
+    check_pending()
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -87,6 +120,14 @@ def test_two_rank_gloo_search_equals_unsharded(oracle):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), 6001, 128, 25, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_two_rank_gloo_bucketed_exchange(oracle):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_bucketed, args=(world, _free_port(), 5003, 128, 12, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
 

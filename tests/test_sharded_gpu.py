@@ -54,6 +54,19 @@ def _worker(rank, world, port, total_n, bits, k, ret):
     torch.cuda.synchronize()
     for r in (3, 4):                         # the last two batches sit in the two buffer sets
         ok = ok and bool(np.array_equal(outs[r][1].cpu().numpy().view(np.uint64), np.roll(exp, r, axis=0)))
+    # bucketed exchange: three batches per all-gather + merge, the fourth and fifth completed by flush()
+    sb = ShardedSearch(bits, total_n, rank=rank, world=world, device=0, bucket=3, backend=ss.backend)
+    held = []
+    for r in range(5):
+        qq = np.roll(q, r, axis=0).copy()
+        held.append((r, sb.search(torch.from_numpy(qq).cuda(), k)[0]))
+        if r == 2 or r == 4:
+            if r == 4:
+                sb.flush()
+            torch.cuda.synchronize()
+            for rr, o in held:
+                ok = ok and bool(np.array_equal(o.cpu().numpy().view(np.uint64), np.roll(exp, rr, axis=0)))
+            held = []
     ret[rank] = ok
     ss.close()
     dist.destroy_process_group()

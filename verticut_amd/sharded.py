@@ -61,10 +61,16 @@ class ShardedSearch:
     """
 
     def __init__(self, bits, total_n, rank=None, world=None, n_tables=0, device=None, group=None, backend=None,
-                 pipelined=False, force_exchange=False, **engine_kw):
+                 pipelined=False, force_exchange=False, bucket=1, **engine_kw):
         """pipelined=True: the all-gather + merge of batch i run on a side stream while batch i+1 is already being
-        scanned; results of a call are then ordered on the caller's stream only after flush() (or two calls later)."""
+        scanned; results of a call are then ordered on the caller's stream only after flush() (or two calls later).
+        bucket=B > 1: the per-shard top-k of B consecutive batches are exchanged with ONE all-gather + merge (the
+        collective is latency-bound at 6.4 KB per rank, so B batches cost the same as one); the tensors a call returns
+        are filled in when its bucket is exchanged -- after B - 1 more calls, or flush() -- and reused by the next bucket."""
         self.group = group
+        self.bucket = max(1, int(bucket))
+        self._fill = 0
+        self._bkey = None
         self.pipelined = pipelined
         self.force_exchange = force_exchange   # run the all-gather + merge even with one rank (exercises RCCL on 1 GPU)
         self._side = None
@@ -139,14 +145,47 @@ class ShardedSearch:
         return out, ocnt
 
     def flush(self):
-        """make the caller's current stream wait for every exchange still in flight (pipelined mode)"""
+        """complete what is pending: exchange a partly filled bucket, and make the caller's current stream wait for
+        every side-stream exchange still in flight (pipelined mode)"""
+        if self._fill:
+            self._exchange_bucket()
         for ev in self._done:
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
 
+    def _exchange_bucket(self):
+        _, nq, k, local, lcnt, gath, out, ocnt = self._bkey
+        rows = self._fill * nq
+        self._fill = 0
+        g = gath.view(-1, k)[: self.world * rows]                       # [world][rows][k], contiguous prefix
+        dist.all_gather_into_tensor(g, local[:rows], group=self.group)   # rank-major concat
+        self.backend.merge(g.view(self.world, rows, k), self.world, rows, k, out[:rows], ocnt[:rows])
+
+    def _search_bucketed(self, queries, k, mode):
+        nq, dev, B = queries.shape[0], queries.device, self.bucket
+        key = (nq, k, str(dev), mode)
+        if self._bkey is None or self._bkey[0] != key:
+            if self._fill:
+                self._exchange_bucket()                                   # shape changed mid-bucket
+            self._bkey = (key, nq, k, torch.empty((B * nq, k), dtype=torch.int64, device=dev),
+                          torch.empty((B * nq,), dtype=torch.int32, device=dev),
+                          torch.empty((self.world, B * nq, k), dtype=torch.int64, device=dev),
+                          torch.empty((B * nq, k), dtype=torch.int64, device=dev),
+                          torch.empty((B * nq,), dtype=torch.int32, device=dev))
+        _, _, _, local, lcnt, gath, out, ocnt = self._bkey
+        lo, hi = self._fill * nq, (self._fill + 1) * nq
+        self.backend.local_topk(queries, k, local[lo:hi], lcnt[lo:hi], mode)
+        self._fill += 1
+        if self._fill == B:
+            self._exchange_bucket()
+        return out[lo:hi], ocnt[lo:hi]
+
     def search(self, queries, k, mode=vc.MODE_LINEAR):
-        if self.pipelined and (self.world > 1 or self.force_exchange) and queries.is_cuda:
+        exchange = self.world > 1 or self.force_exchange
+        if self.pipelined and exchange and queries.is_cuda:
             return self._search_pipelined(queries, k, mode)
+        if self.bucket > 1 and exchange:
+            return self._search_bucketed(queries, k, mode)
         nq = queries.shape[0]
         local, lcnt, gath, out, ocnt = self._buffers(nq, k, queries.device)
         self.backend.local_topk(queries, k, local, lcnt, mode)
