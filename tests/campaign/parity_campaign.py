@@ -1,15 +1,15 @@
-"""Dev tool (GPU box): a long seeded parity campaign of the linear verify path against the oracle, beyond what the
-regular test-suite has time for: databases of several million codes (many chunks per persistent block, threshold
+"""Test infrastructure (GPU box, run by hand; not collected by pytest): a long seeded parity campaign of the linear
+verify path against the oracle, beyond what the regular test-suite has time for: databases of several million codes (many chunks per persistent block, threshold
 feedback, re-cuts), every code width, ragged sizes, duplicates (ring overflow + recovery), big k, big tiles, and the
 selectable kernel shapes.  Prints one line per case and a summary; exit code 1 on the first mismatch.
-usage: python tools/parity_campaign.py [n_cases=120] [seed0=0]   (test infrastructure: imports oracle/)"""
+usage: python tests/campaign/parity_campaign.py [n_cases=120] [seed0=0]   (test infrastructure: imports oracle/)"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import vc_oracle as oracle  # noqa: E402

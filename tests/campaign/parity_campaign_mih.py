@@ -1,16 +1,16 @@
-"""Dev tool (GPU box): seeded parity campaign of the MIH path (probe, bitmap, verify, commit, stop rule, radius search)
-against the oracle's restatement of search_worker.cc, beyond the regular suite: every substring width, the reference
+"""Test infrastructure (GPU box, run by hand; not collected by pytest): seeded parity campaign of the MIH path
+(probe, bitmap, verify, commit, stop rule, radius search) against the oracle's restatement of search_worker.cc, beyond the regular suite: every substring width, the reference
 quirk flags, exact and approximate mode, attached bitmap, ragged sizes, id bases, big k, duplicate-heavy data.
 Checks per query: the SURVEY 8c contract (distance multiset + id set below the k-th distance), radius / n_sub_reads /
 n_local_reads / distinct-candidate statistics, and the engine's canonical rule exactly.
-usage: python tools/parity_campaign_mih.py [n_cases=200] [seed0=0]   (test infrastructure: imports oracle/)"""
+usage: python tests/campaign/parity_campaign_mih.py [n_cases=200] [seed0=0]   (test infrastructure: imports oracle/)"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import vc_oracle as oracle  # noqa: E402

@@ -485,7 +485,7 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
 // count(<= hi):
 //   * probe = hi; the k-th best of what fitted becomes the new hi.  With entries arriving in random order that
 //     quarters the survivors per round (cap >= 4k); but arrival order is NOT random (the same early waves deliver
-//     ids just under the limit round after round: tools/parity_campaign.py case 259 needed > 64 rounds), so
+//     ids just under the limit round after round: tests/campaign/parity_campaign.py case 259 needed > 64 rounds), so
 //   * whenever a round fails to halve the survivors the next probe bisects (lo, hi] instead: fewer than k items
 //     below it -> lo = probe; otherwise hi = min(probe, k-th best of what fitted).
 // Each bisection halves a 64-bit interval, the other steps never widen it: it ends.

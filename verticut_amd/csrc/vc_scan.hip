@@ -502,7 +502,7 @@ struct VcRingSrc {
   __device__ uint32_t slot(uint32_t b) const { return list ? list[b] : b; }
   // Pre-filter by the final threshold -- but not when the ring overflowed: tau comes from the histogram of ALL
   // survivors, stored or not, so it can lie below every entry that did fit (early arrivals under a loose tau), and
-  // the recovery pass needs the k-th best of what fitted as its bound (found by tools/parity_campaign.py: k = 1,
+  // the recovery pass needs the k-th best of what fitted as its bound (found by tests/campaign/parity_campaign.py: k = 1,
   // cap = 4, thousands of duplicates -> empty row -> no bound -> "recovery did not converge").
   __device__ uint64_t bound(uint32_t q) const {
     return (tau && count[q] <= cap) ? (((uint64_t)tau[q] + 1) << 32) : VC_PACK_INF;
