@@ -189,14 +189,15 @@ def test_config_struct_layout_matches_header(vc):
 
 
 def test_product_never_imports_the_oracle():
-    """the oracle is the checker, never the thing shipped: nothing under verticut_amd/ or include/ names it."""
+    """the oracle is the checker, never the thing shipped: nothing under verticut_amd/, include/ or tools/ names it
+    (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may)."""
     bad = []
-    for base in ("verticut_amd", "include"):
+    for base in ("verticut_amd", "include", "tools"):
         for dp, _, files in os.walk(os.path.join(ROOT, base)):
             for fn in files:
                 if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".cc")):
                     src = open(os.path.join(dp, fn), errors="replace").read()
-                    if re.search(r"^\s*(from|import)\s+oracle|libvcoracle|libvcref|dlopen\(.*oracle", src, flags=re.M):
+                    if re.search(r"^\s*(from|import)\s+(oracle|vc_oracle)|libvcoracle|libvcref|dlopen\(.*oracle", src, flags=re.M):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
 
