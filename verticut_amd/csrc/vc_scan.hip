@@ -246,9 +246,10 @@ __global__ void __launch_bounds__(64) vc_tau_init_kernel(const uint32_t* __restr
 //
 // Filter: per query a distance threshold tau (k-th best distance known so far, chip-wide).  Hot loop =
 // xor, v_bcnt accumulate, min, one compare per query.  Rare path (a lane beat tau): refresh tau from
-// HBM, ballot + prefix-sum the survivors of the wave, reserve ring space with ONE atomic per wave,
-// store packed dist<<32|id (search_worker.cc:254-256), bump the chip-wide distance histogram and
-// re-derive tau from it (smallest d whose cumulative count reaches k).  tau only ever decreases and a
+// HBM, ballot + prefix-sum the survivors of the wave, reserve ring space with ONE atomic per wave and
+// surviving item pair, store packed dist<<32|id (search_worker.cc:254-256), bump the chip-wide distance
+// histogram and, every VC_SCAN_RECUT_EVERY ring entries, re-derive tau from it (smallest d whose
+// cumulative count reaches k).  tau only ever decreases and a
 // stale tau is merely conservative, so no ordering between waves is needed for correctness.
 // ------------------------------------------------------------------------------------------
 // Rare path of the verify kernel (a lane beat the threshold).  It is inlined -- an out-of-line call would have to
