@@ -392,29 +392,35 @@ int vc_get_timing(const vc_engine* ce, vc_timing* t) {
 
 // ---- LINEAR: linear_search.cc:39-64 for a batch of queries ------------------------------------------
 struct LinearBufs {
-  uint32_t hs, QT, cap;
+  uint32_t hs, QT, GQ, cap;   // histogram stride, queries per tile (one verify launch), per group (one bootstrap), ring entries
   size_t state_words;
   uint32_t *d_count, *d_hist, *d_shist, *d_shist2, *d_tau;
 };
 
+// Queries whose bootstrap is done by ONE pair of sampling launches: the tiles of a group share them (the stage
+// kernels read the sampled prefix once per 32 queries instead of once per tile) and one select launch.
+#define VC_GROUP_QUERIES 64u
+
 static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
   b->hs = (e->bits + 1 + 7) & ~7u;
   b->QT = std::min(e->qtile, nq);
+  b->GQ = std::min(nq, std::max(b->QT, VC_GROUP_QUERIES / b->QT * b->QT));   // whole tiles, >= one tile
   b->cap = std::max(e->cap, 4 * k);
-  b->state_words = (size_t)b->QT * (1 + (1 + 2 * (size_t)VC_SHIST_COPIES) * (size_t)b->hs + 1);
+  b->state_words = (size_t)b->GQ * (1 + (1 + 2 * (size_t)VC_SHIST_COPIES) * (size_t)b->hs + 1);
   int rc;
   if ((rc = grow(e, &e->d_state, &e->state_bytes, b->state_words * 4))) return rc;
-  if ((rc = grow(e, &e->d_ring, &e->ring_bytes, (size_t)b->QT * b->cap * 8))) return rc;
+  if ((rc = grow(e, &e->d_ring, &e->ring_bytes, (size_t)b->GQ * b->cap * 8))) return rc;
   b->d_count = e->d_state;
-  b->d_hist = b->d_count + b->QT;
-  b->d_shist = b->d_hist + (size_t)b->QT * b->hs;
-  b->d_shist2 = b->d_shist + (size_t)VC_SHIST_COPIES * b->QT * b->hs;
-  b->d_tau = b->d_shist2 + (size_t)VC_SHIST_COPIES * b->QT * b->hs;
+  b->d_hist = b->d_count + b->GQ;
+  b->d_shist = b->d_hist + (size_t)b->GQ * b->hs;
+  b->d_shist2 = b->d_shist + (size_t)VC_SHIST_COPIES * b->GQ * b->hs;
+  b->d_tau = b->d_shist2 + (size_t)VC_SHIST_COPIES * b->GQ * b->hs;
   return VC_OK;
 }
 
-// one verify launch for a tile whose tau is already set; d_limit may be null
-static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint32_t qt, uint32_t k, const uint64_t* d_limit) {
+// one verify launch for a tile whose tau is already set (the tile's state starts at query t0 of the group); d_limit may be null
+static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint32_t qt, uint32_t k, const uint64_t* d_limit,
+                     uint32_t t0 = 0) {
   const VcScanShape sh = vc_scan_pick_shape(e->W, qt, nullptr);
   VcScanParams p{};
   p.cols = e->d_cols;
@@ -427,10 +433,10 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
   p.cap = b.cap;
   p.hist_stride = b.hs;
   p.queries = dq;
-  p.tau = b.d_tau;
-  p.count = b.d_count;
-  p.hist = b.d_hist;
-  p.buf = e->d_ring;
+  p.tau = b.d_tau + t0;
+  p.count = b.d_count + t0;
+  p.hist = b.d_hist + (size_t)t0 * b.hs;
+  p.buf = e->d_ring + (size_t)t0 * b.cap;
   p.limit = d_limit;
   if (const char* w = getenv("VC_SCAN_WRAP")) p.wrap = (uint32_t)atoi(w);   // diagnostic, results are wrong by design
   if (const char* w = getenv("VC_SCAN_DIAG")) p.diag = (uint32_t)atoi(w);   // diagnostic, results are wrong by design
@@ -462,18 +468,19 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
   if (sample2 < 4 * sample) sample2 = 0;
   if (const char* s2 = getenv("VC_SAMPLE2")) sample2 = std::min<uint64_t>(e->n, strtoull(s2, nullptr, 10));   // dev/test knob
   if (sample2) sample = std::min<uint64_t>(sample, std::max<uint64_t>(65536, 64ull * k));   // stage 1 only has to seed stage 2
-  for (uint32_t q0 = 0; q0 < nq; q0 += b.QT) {
-    const uint32_t qt = std::min(b.QT, nq - q0);
-    const uint64_t* dq = d_q + (size_t)q0 * e->W;
+  for (uint32_t g0 = 0; g0 < nq; g0 += b.GQ) {
+    const uint32_t gq = std::min(b.GQ, nq - g0);
+    const uint64_t* dg = d_q + (size_t)g0 * e->W;
     VC_HIP(e, hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
-    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dq, qt, b.d_shist, b.hs, k, e->bits, b.d_tau, false,
+    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dg, gq, b.d_shist, b.hs, k, e->bits, b.d_tau, false,
                                     e->n_cu, e->stream));
     if (sample2)
-      VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample2, dq, qt, b.d_shist2, b.hs, k, e->bits, b.d_tau, true,
+      VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample2, dg, gq, b.d_shist2, b.hs, k, e->bits, b.d_tau, true,
                                       e->n_cu, e->stream));
-    if ((rc = scan_tile(e, b, dq, qt, k, nullptr))) return rc;
-    VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, qt, k, d_out + (size_t)q0 * k, d_cnt + q0, e->stream));
-    if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + q0, b.d_count, qt * 4, hipMemcpyDeviceToDevice, e->stream));
+    for (uint32_t t0 = 0; t0 < gq; t0 += b.QT)
+      if ((rc = scan_tile(e, b, dg + (size_t)t0 * e->W, std::min(b.QT, gq - t0), k, nullptr, t0))) return rc;
+    VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, gq, k, d_out + (size_t)g0 * k, d_cnt + g0, e->stream));
+    if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + g0, b.d_count, gq * 4, hipMemcpyDeviceToDevice, e->stream));
   }
   return VC_OK;
 }
