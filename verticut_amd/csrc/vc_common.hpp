@@ -81,4 +81,10 @@ struct VcScanParams {
   uint64_t* buf;            // [qt][cap] appended packed candidates
   const uint64_t* limit;    // optional [qt]: append only packed values <= limit[q] (ring-overflow recovery)
   uint32_t diag;            // diagnostic only (VC_SCAN_DIAG): N > 0 replaces the verify arithmetic by s_sleep N per query
+  uint32_t qs;              // stride, in words, between consecutive queries' entries of tau[] and count[] (>= 1)
 };
+// The linear path gives every query its own 128-byte line for its threshold and for its ring cursor: both are read /
+// updated coherently by every wave that enters the rare path, coherent traffic to one line is served by ONE memory
+// channel, and eight queries sharing a line overloaded that channel enough to slow the whole (channel-interleaved)
+// code stream by 5-14 % depending on where the allocation happened to land (tools/placement_probe.py).
+#define VC_QUERY_LINE_WORDS 32u

@@ -406,15 +406,17 @@ static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
   b->QT = std::min(e->qtile, nq);
   b->GQ = std::min(nq, std::max(b->QT, VC_GROUP_QUERIES / b->QT * b->QT));   // whole tiles, >= one tile
   b->cap = std::max(e->cap, 4 * k);
-  b->state_words = (size_t)b->GQ * (1 + (1 + 2 * (size_t)VC_SHIST_COPIES) * (size_t)b->hs + 1);
+  // count[GQ] and tau[GQ] hold one 128-byte line per query (VC_QUERY_LINE_WORDS); the histograms are dense
+  const size_t hist_words = (((size_t)b->GQ * (1 + 2 * (size_t)VC_SHIST_COPIES) * b->hs) + 31) & ~(size_t)31;   // keeps tau[] line-aligned
+  b->state_words = (size_t)b->GQ * 2 * VC_QUERY_LINE_WORDS + hist_words;
   int rc;
   if ((rc = grow(e, &e->d_state, &e->state_bytes, b->state_words * 4))) return rc;
   if ((rc = grow(e, &e->d_ring, &e->ring_bytes, (size_t)b->GQ * b->cap * 8))) return rc;
   b->d_count = e->d_state;
-  b->d_hist = b->d_count + b->GQ;
+  b->d_hist = b->d_count + (size_t)b->GQ * VC_QUERY_LINE_WORDS;
   b->d_shist = b->d_hist + (size_t)b->GQ * b->hs;
   b->d_shist2 = b->d_shist + (size_t)VC_SHIST_COPIES * b->GQ * b->hs;
-  b->d_tau = b->d_shist2 + (size_t)VC_SHIST_COPIES * b->GQ * b->hs;
+  b->d_tau = b->d_hist + hist_words;
   return VC_OK;
 }
 
@@ -433,8 +435,9 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
   p.cap = b.cap;
   p.hist_stride = b.hs;
   p.queries = dq;
-  p.tau = b.d_tau + t0;
-  p.count = b.d_count + t0;
+  p.qs = VC_QUERY_LINE_WORDS;
+  p.tau = b.d_tau + (size_t)t0 * VC_QUERY_LINE_WORDS;
+  p.count = b.d_count + (size_t)t0 * VC_QUERY_LINE_WORDS;
   p.hist = b.d_hist + (size_t)t0 * b.hs;
   p.buf = e->d_ring + (size_t)t0 * b.cap;
   p.limit = d_limit;
@@ -472,15 +475,17 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
     const uint32_t gq = std::min(b.GQ, nq - g0);
     const uint64_t* dg = d_q + (size_t)g0 * e->W;
     VC_HIP(e, hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
-    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dg, gq, b.d_shist, b.hs, k, e->bits, b.d_tau, false,
+    VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dg, gq, b.d_shist, b.hs, k, e->bits, b.d_tau, VC_QUERY_LINE_WORDS, false,
                                     e->n_cu, e->stream));
     if (sample2)
-      VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample2, dg, gq, b.d_shist2, b.hs, k, e->bits, b.d_tau, true,
+      VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample2, dg, gq, b.d_shist2, b.hs, k, e->bits, b.d_tau, VC_QUERY_LINE_WORDS, true,
                                       e->n_cu, e->stream));
     for (uint32_t t0 = 0; t0 < gq; t0 += b.QT)
       if ((rc = scan_tile(e, b, dg + (size_t)t0 * e->W, std::min(b.QT, gq - t0), k, nullptr, t0))) return rc;
-    VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, gq, k, d_out + (size_t)g0 * k, d_cnt + g0, e->stream));
-    if (d_raw) VC_HIP(e, hipMemcpyAsync(d_raw + g0, b.d_count, gq * 4, hipMemcpyDeviceToDevice, e->stream));
+    VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, VC_QUERY_LINE_WORDS, gq, k, d_out + (size_t)g0 * k,
+                                    d_cnt + g0, e->stream));
+    if (d_raw)   // one counter per 128-byte line -> dense
+      VC_HIP(e, hipMemcpy2DAsync(d_raw + g0, 4, b.d_count, VC_QUERY_LINE_WORDS * 4, 4, gq, hipMemcpyDeviceToDevice, e->stream));
   }
   return VC_OK;
 }
@@ -540,14 +545,14 @@ static int linear_recover(vc_engine* e, const uint64_t* d_q, uint32_t k, const s
       }
       RC(hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
       RC(hipMemcpyAsync(d_lim, lim.data(), qt * 8, hipMemcpyHostToDevice, e->stream));
-      RC(hipMemcpyAsync(b.d_tau, tau.data(), qt * 4, hipMemcpyHostToDevice, e->stream));
+      RC(hipMemcpy2DAsync(b.d_tau, VC_QUERY_LINE_WORDS * 4, tau.data(), 4, 4, qt, hipMemcpyHostToDevice, e->stream));
       if ((rc = scan_tile(e, b, d_rq, qt, k, d_lim))) { cleanup(); return rc; }
-      RC(vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, qt, k, d_rout, d_rcnt, e->stream));
+      RC(vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, VC_QUERY_LINE_WORDS, qt, k, d_rout, d_rcnt, e->stream));
       std::vector<uint64_t> rout((size_t)qt * k);
       std::vector<uint32_t> rcnt(qt), raw(qt);
       RC(hipMemcpyAsync(rout.data(), d_rout, rout.size() * 8, hipMemcpyDeviceToHost, e->stream));
       RC(hipMemcpyAsync(rcnt.data(), d_rcnt, qt * 4, hipMemcpyDeviceToHost, e->stream));
-      RC(hipMemcpyAsync(raw.data(), b.d_count, qt * 4, hipMemcpyDeviceToHost, e->stream));
+      RC(hipMemcpy2DAsync(raw.data(), 4, b.d_count, VC_QUERY_LINE_WORDS * 4, 4, qt, hipMemcpyDeviceToHost, e->stream));
       RC(hipStreamSynchronize(e->stream));
       for (uint32_t i = 0; i < qt; ++i) {
         Rec r = todo[t0 + i];

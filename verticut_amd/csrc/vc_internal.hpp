@@ -23,12 +23,12 @@ hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t
 // distances <= tau[q]), then tau[q] = k-th smallest sampled distance.  d_shist [qt][hist_stride] must be zero.
 hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
-                                 uint32_t k, uint32_t bits, uint32_t* d_tau, bool refine, uint32_t n_cu, hipStream_t s);
+                                 uint32_t k, uint32_t bits, uint32_t* d_tau, uint32_t qs, bool refine, uint32_t n_cu, hipStream_t s);
 // grid = min(chunks, CUs x resident blocks per CU, want_blocks if non-zero)
 hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, hipStream_t s);
 // ring -> sorted top-k (per query); out padded with VC_PACK_INF
 // d_tau (nullable): final per-query distance thresholds of the scan -- farther entries are dropped before sorting
-hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_tau,
+hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_tau, uint32_t qs,
                                  uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s);
 // same, for the ring slots named in d_list (outputs indexed by slot)
 hipError_t vc_launch_select_ring_list(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_list,

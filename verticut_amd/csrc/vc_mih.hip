@@ -911,7 +911,7 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
         VcScanParams p{};
         p.cols = d_cols; p.stride = stride; p.n = n; p.nchunks = (n + sh.chunk_items() - 1) / sh.chunk_items();
         p.id_base = id_base; p.qt = qt; p.k = 0xFFFFFFFFu;   // never re-derive tau: it is the fixed radius
-        p.cap = cap; p.hist_stride = hs; p.queries = d_q + (size_t)q0 * W; p.tau = d_tau; p.count = d_count;
+        p.cap = cap; p.hist_stride = hs; p.queries = d_q + (size_t)q0 * W; p.tau = d_tau; p.count = d_count; p.qs = 1;
         p.hist = d_hist; p.buf = d_ring;
         R_CHECK(vc_launch_scan(p, W, n_cu, 0, s));
       }

@@ -165,6 +165,7 @@ struct VcSampleParams {
   uint32_t* shist;           // [VC_SHIST_COPIES][qt][hs] zeroed by the caller; block b flushes into copy b % COPIES
   const uint32_t* tau;       // [qt] refine: only distances <= tau[q] are counted
   uint32_t qt, hs, refine;
+  uint32_t qs;               // words between consecutive queries' tau entries
 };
 
 // Stage kernel of the threshold bootstrap.  Blocks histogram their share of the prefix in LDS and flush with one
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(256) vc_sample_hist_kernel(const VcSampleParam
   uint32_t* sthr = lh + (size_t)VC_SAMPLE_QSUB * hs;                   // [nq] only distances <= thr are counted
   for (uint32_t i = threadIdx.x; i < nq * W; i += blockDim.x) sq[i] = p.queries[(uint64_t)q0 * W + i];
   for (uint32_t i = threadIdx.x; i < nq * hs; i += blockDim.x) lh[i] = 0;
-  for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) sthr[i] = p.refine ? p.tau[q0 + i] : 0xFFFFFFFFu;
+  for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) sthr[i] = p.refine ? p.tau[(size_t)(q0 + i) * p.qs] : 0xFFFFFFFFu;
   __syncthreads();
 
   const uint64_t npairs = (p.s_items + 1) / 2;
@@ -226,10 +227,12 @@ __global__ void __launch_bounds__(256) vc_sample_hist_kernel(const VcSampleParam
 // everything; refining stage without a cut = keep the previous bound.  One wave per query.  (A "last block to
 // arrive" epilogue in the stage kernel was tried instead of this launch: 2048 tickets on one counter cost 0.1 ms.)
 __global__ void __launch_bounds__(64) vc_tau_init_kernel(const uint32_t* __restrict__ shist, uint32_t hs, uint32_t k,
-                                                         uint32_t bits, uint32_t* __restrict__ tau, uint32_t refine) {
+                                                         uint32_t bits, uint32_t* __restrict__ tau, uint32_t refine,
+                                                         uint32_t qs) {
   const uint32_t q = blockIdx.x;
   const uint32_t cut = vc_hist_cut(shist + (uint64_t)q * hs, bits + 1, k, false, VC_SHIST_COPIES, (uint64_t)gridDim.x * hs);
-  if (threadIdx.x == 0) tau[q] = (cut == 0xFFFFFFFFu) ? (refine ? tau[q] : bits) : (refine ? min(cut, tau[q]) : cut);
+  uint32_t* tq = tau + (size_t)q * qs;
+  if (threadIdx.x == 0) *tq = (cut == 0xFFFFFFFFu) ? (refine ? *tq : bits) : (refine ? min(cut, *tq) : cut);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -265,7 +268,7 @@ struct VcScanRare {
   uint32_t* hist;
   uint64_t* buf;
   const uint64_t* limit;
-  uint32_t id_base, k, cap, hist_stride;
+  uint32_t id_base, k, cap, hist_stride, qs;
 };
 
 template <int W, int U, int BLK>
@@ -276,7 +279,8 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
   // of all U pairs (invariant across the query loop) to tile level and keeps them alive through the hot loop.
   uint32_t tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
-  uint32_t t = vc_ld_relaxed(p.tau + q);
+  uint32_t* const tau_q = p.tau + (size_t)q * p.qs;
+  uint32_t t = vc_ld_relaxed(tau_q);
   const uint64_t lim = p.limit ? p.limit[q] : VC_PACK_INF;   // recovery pass: exact packed bound (ties cannot refill the ring)
   uint64_t* ring = p.buf + (uint64_t)q * p.cap;
   uint32_t* hist = p.hist + (uint64_t)q * p.hist_stride;
@@ -299,7 +303,7 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
     uint32_t total;
     uint32_t slot = vc_wave_excl_scan(cnt, total);
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(p.count + q, total);
+    if (lane == 0) base = atomicAdd(p.count + (size_t)q * p.qs, total);
     base = __builtin_amdgcn_readfirstlane(base);
     slot += base;
     seen = base + total;
@@ -321,7 +325,7 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
     const uint32_t cut = vc_hist_cut(hist, t + 1, p.k, true);
     if (cut < t) {
       t = cut;
-      if (lane == 0) atomicMin(p.tau + q, t);
+      if (lane == 0) atomicMin(tau_q, t);
     }
   }
   if (lane == 0) st[q] = t;
@@ -344,11 +348,11 @@ __global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : ((W >= 4 || NB * U * W 
   uint64_t* sq = (uint64_t*)smem;                             // [qt][W]  query tile
   uint32_t* st = (uint32_t*)(smem + (size_t)p.qt * W * 8);    // [qt]     block-local copy of tau
   for (uint32_t i = threadIdx.x; i < p.qt * W; i += BLK) sq[i] = p.queries[i];
-  for (uint32_t i = threadIdx.x; i < p.qt; i += BLK) st[i] = (VC_SCAN_DIAGNOSTICS && p.wrap) ? 0u : vc_ld_relaxed(p.tau + i);  // wrap: rare path off
+  for (uint32_t i = threadIdx.x; i < p.qt; i += BLK) st[i] = (VC_SCAN_DIAGNOSTICS && p.wrap) ? 0u : vc_ld_relaxed(p.tau + (size_t)i * p.qs);  // wrap: rare path off
   __syncthreads();
 
   constexpr uint64_t CH = 2ull * BLK * U;
-  const VcScanRare rare{p.n, p.tau, p.count, p.hist, p.buf, p.limit, p.id_base, p.k, p.cap, p.hist_stride};
+  const VcScanRare rare{p.n, p.tau, p.count, p.hist, p.buf, p.limit, p.id_base, p.k, p.cap, p.hist_stride, p.qs};
   vc_u64x2 ra[U][W], rb[NB >= 2 ? U : 1][W], rc[NB >= 3 ? U : 1][W];
 
   // Prefetch cursor: the chunk the next load() fetches.  Tile loads are issued by hand (inline asm): the address is a
@@ -500,16 +504,17 @@ struct VcRingSrc {
   const uint32_t* list;   // optional: block b serves ring slot list[b]
   uint32_t mark_overflow; // report count = UINT32_MAX when the ring overflowed (row is then only an upper bound)
   const uint32_t* tau;    // optional final distance thresholds: entries farther than tau[q] cannot be in the top-k
+  uint32_t qs;            // words between consecutive queries' entries of count[] and tau[]
   __device__ uint32_t slot(uint32_t b) const { return list ? list[b] : b; }
   // Pre-filter by the final threshold -- but not when the ring overflowed: tau comes from the histogram of ALL
   // survivors, stored or not, so it can lie below every entry that did fit (early arrivals under a loose tau), and
   // the recovery pass needs the k-th best of what fitted as its bound (found by tests/campaign/parity_campaign.py: k = 1,
   // cap = 4, thousands of duplicates -> empty row -> no bound -> "recovery did not converge").
   __device__ uint64_t bound(uint32_t q) const {
-    return (tau && count[q] <= cap) ? (((uint64_t)tau[q] + 1) << 32) : VC_PACK_INF;
+    return (tau && count[(size_t)q * qs] <= cap) ? (((uint64_t)tau[(size_t)q * qs] + 1) << 32) : VC_PACK_INF;
   }
-  __device__ bool overflowed(uint32_t q) const { return mark_overflow && count[q] > cap; }
-  __device__ uint32_t size(uint32_t q) const { return min(count[q], cap); }
+  __device__ bool overflowed(uint32_t q) const { return mark_overflow && count[(size_t)q * qs] > cap; }
+  __device__ uint32_t size(uint32_t q) const { return min(count[(size_t)q * qs], cap); }
   __device__ uint64_t get(uint32_t q, uint32_t i) const { return buf[(uint64_t)q * cap + i]; }
 };
 struct VcListsSrc {
@@ -765,10 +770,10 @@ hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t
 
 hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
-                                 uint32_t k, uint32_t bits, uint32_t* d_tau, bool refine, uint32_t n_cu, hipStream_t s) {
+                                 uint32_t k, uint32_t bits, uint32_t* d_tau, uint32_t qs, bool refine, uint32_t n_cu, hipStream_t s) {
   if (qt == 0) return hipSuccess;
   if (s_items == 0) {   // nothing to sample: the cut of the (zero) histogram = "accept everything"
-    hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u);
+    hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u, qs);
     return hipGetLastError();
   }
   const uint32_t gy = (qt + VC_SAMPLE_QSUB - 1) / VC_SAMPLE_QSUB;
@@ -777,7 +782,7 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
   if (const char* g = getenv("VC_SAMPLE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(g));   // dev knob
   const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * per_cu);
   const size_t lds = (size_t)VC_SAMPLE_QSUB * W * 8 + (size_t)VC_SAMPLE_QSUB * hist_stride * 4 + VC_SAMPLE_QSUB * 4;
-  VcSampleParams p{cols, stride, s_items, d_queries, d_shist, d_tau, qt, hist_stride, refine ? 1u : 0u};
+  VcSampleParams p{cols, stride, s_items, d_queries, d_shist, d_tau, qt, hist_stride, refine ? 1u : 0u, qs};
 #define VC_SH_CASE(W_)                                                                                   \
   case W_:                                                                                               \
     hipLaunchKernelGGL((vc_sample_hist_kernel<W_>), dim3(gx, gy), dim3(256), lds, s, p);                  \
@@ -793,7 +798,7 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
 #undef VC_SH_CASE
   hipError_t r = hipGetLastError();
   if (r != hipSuccess) return r;
-  hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u);
+  hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u, qs);
   return hipGetLastError();
 }
 
@@ -811,9 +816,9 @@ hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint
 }
 
 hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_tau,
-                                 uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
+                                 uint32_t qs, uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
   if (nq == 0) return hipSuccess;
-  VcRingSrc src{d_buf, d_count, cap, nullptr, 1u, d_tau};
+  VcRingSrc src{d_buf, d_count, cap, nullptr, 1u, d_tau, qs};
   hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(nq), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
   return hipGetLastError();
 }
@@ -821,7 +826,7 @@ hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint
 hipError_t vc_launch_select_ring_list(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_list,
                                       uint32_t n_list, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
   if (n_list == 0) return hipSuccess;
-  VcRingSrc src{d_buf, d_count, cap, d_list, 0u, nullptr};
+  VcRingSrc src{d_buf, d_count, cap, d_list, 0u, nullptr, 1u};
   hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(n_list), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
   return hipGetLastError();
 }
