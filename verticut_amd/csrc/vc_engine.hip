@@ -463,11 +463,14 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
   int rc = linear_bufs(e, nq, k, &b);
   if (rc) return rc;
   // Threshold bootstrap in two stages.  Stage 1: exact distance histogram of the first `sample` codes -> tau1 (k-th
-  // best of the sample).  Stage 2: histogram of a 32x larger prefix, counting only distances <= tau1 (rare, so it costs
+  // best of the sample).  Stage 2: histogram of an 8x larger prefix, counting only distances <= tau1 (rare, so it costs
   // a plain scan of the prefix) -> tau2.  The tighter start keeps the verify kernel's first steps from flooding the
-  // ring / histogram atomics from every wave at once (measured: ~0.4 ms per launch with stage 1 alone).
+  // ring / histogram atomics from every wave at once.  That flood cost ~0.4 ms per launch while eight queries shared
+  // one line for their ring cursors and one for their thresholds, and the optimum stage-2 sample was 8-16 M codes;
+  // with one line per query (VC_QUERY_LINE_WORDS) it costs 1-2 % without any stage 2 and the optimum is flat from
+  // 0.5 M to 4 M codes (profiles/r01_sweeps.md), so the sample is 2 M: 12 us instead of 30.
   uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(262144, 64ull * k));
-  uint64_t sample2 = std::min<uint64_t>(e->n / 16, sample * 32);   // 8.4 M codes at k = 100 (measured optimum 8-16 M)
+  uint64_t sample2 = std::min<uint64_t>(e->n / 16, sample * 8);   // 2.1 M codes at k = 100
   if (sample2 < 4 * sample) sample2 = 0;
   if (const char* s2 = getenv("VC_SAMPLE2")) sample2 = std::min<uint64_t>(e->n, strtoull(s2, nullptr, 10));   // dev/test knob
   if (sample2) sample = std::min<uint64_t>(sample, std::max<uint64_t>(65536, 64ull * k));   // stage 1 only has to seed stage 2
