@@ -38,6 +38,11 @@ struct VcTableView {
   const uint32_t* ids;
   const uint32_t* bitmap;
   const uint32_t* blockrank;  // s == 32 only
+  // Optional copy of the codes in THIS table's bucket order (word j of the pos-th entry at bcodes[j*n + pos]), built
+  // for substrings <= 16 bit: their buckets hold thousands of items (1526 at 1e8 codes, s = 16), and verifying a
+  // bucket through ids[] -> cols[] is an 8-byte gather per word that moves a 64-byte sector each; from the copy it is
+  // a contiguous stream.  32-bit substrings keep gathering (0.02 items per bucket).
+  const uint64_t* bcodes;
   uint32_t n_unique;
   uint32_t pad;
 };
@@ -49,6 +54,15 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // build kernels
 // ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mih_bcodes_kernel(const uint64_t* __restrict__ cols, uint64_t stride, uint32_t W,
+                                                         const uint32_t* __restrict__ ids, uint64_t n,
+                                                         uint64_t* __restrict__ out) {
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * W; e += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t j = e / n, pos = e - j * n;
+    out[e] = cols[j * stride + ids[pos]];
+  }
+}
+
 __global__ void __launch_bounds__(256) mih_keys_kernel(const uint64_t* __restrict__ col, uint64_t n, uint32_t shift,
                                                        uint32_t mask, uint32_t* __restrict__ keys,
                                                        uint32_t* __restrict__ vals) {
@@ -132,6 +146,7 @@ struct ProbeParams {
   const uint32_t* list;      // slots to process
   MihState st;
   uint32_t r, nkeys, m, sbits, id_base, flags, cap, count_seen;
+  uint64_t n;                // items in the index (stride of the bucket-order code copies)
 };
 
 // lookup of bucket (t, key): start offset and length (0 = PROXY_NOT_FOUND)
@@ -297,10 +312,16 @@ __global__ void __launch_bounds__(MIH_BLK) mih_probe_kernel(const ProbeParams p)
         const uint32_t mid = (lo + hi) >> 1;
         if (s_pref[mid] <= e) lo = mid; else hi = mid;
       }
-      const uint32_t local = tv.ids[s_off[lo] + (e - s_pref[lo])];
+      const uint32_t pos = s_off[lo] + (e - s_pref[lo]);
+      const uint32_t local = tv.ids[pos];
       uint64_t x[W];
+      if (tv.bcodes) {
 #pragma unroll
-      for (int j = 0; j < W; ++j) x[j] = p.cols[(uint64_t)j * p.stride + local] ^ qw[j];
+        for (int j = 0; j < W; ++j) x[j] = tv.bcodes[(uint64_t)j * p.n + pos] ^ qw[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < W; ++j) x[j] = p.cols[(uint64_t)j * p.stride + local] ^ qw[j];
+      }
       // per-substring distances come free with the full distance (compute_hamming_dist, image_tools.h:21-33)
       uint32_t dist = 0;
       emit = true;
@@ -497,6 +518,14 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
     return r;
   };
 
+  // bucket-order code copies for the tables whose buckets are big (see VcTableView::bcodes): m more copies of the
+  // codes, so only while they fit comfortably (dev knob VC_MIH_BCODES=0/1 overrides)
+  bool want_bcodes = sbits <= 16;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (want_bcodes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * W * 8 > free_b / 3) want_bcodes = false;
+    if (const char* v = getenv("VC_MIH_BCODES")) want_bcodes = atoi(v) != 0;
+  }
   const uint64_t nkeyspace = 1ull << sbits;
   const uint64_t bm_words = std::max<uint64_t>(nkeyspace / 32, 8);
   const uint32_t mask = sbits == 32 ? 0xFFFFFFFFu : (uint32_t)(nkeyspace - 1);
@@ -573,6 +602,14 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
     tv.ids = ids;
     tv.bitmap = bitmap;
     tv.blockrank = blockrank;
+    tv.bcodes = nullptr;
+    if (want_bcodes && n) {
+      uint64_t* bc = nullptr;
+      B_CHECK(dalloc((void**)&bc, (size_t)n * W * 8, true));
+      hipLaunchKernelGGL(mih_bcodes_kernel, dim3(grid_for(n * W, n_cu)), dim3(256), 0, s, d_cols, stride, W, ids, n, bc);
+      B_CHECK(hipGetLastError());
+      tv.bcodes = bc;
+    }
     ix->h_tables[t] = tv;
   }
   B_CHECK(hipMalloc((void**)&ix->d_tables, sizeof(VcTableView) * m));
@@ -746,7 +783,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       ProbeParams p{};
       p.cols = d_cols; p.stride = stride; p.tables = ix->d_tables; p.queries = d_q + (size_t)q0 * ix->W;
       p.st = st; p.r = r; p.nkeys = binom_host(S, r); p.m = ix->m; p.sbits = S; p.id_base = ix->id_base;
-      p.flags = ix->flags; p.cap = cap;
+      p.flags = ix->flags; p.cap = cap; p.n = ix->n;
       CommitParams c{};
       c.st = st; c.next_list = nxt; c.redo_list = redo; c.ctr = d_ctr; c.k = k; c.cap = cap; c.r = r; c.sbits = S;
       c.stop_mult = stop_mult; c.approximate = approximate; c.last_shell = r == S;
@@ -899,7 +936,7 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
           ProbeParams p{};
           p.cols = d_cols; p.stride = stride; p.tables = ix->d_tables; p.queries = d_q + (size_t)q0 * W; p.list = list;
           p.st = st; p.r = r; p.nkeys = binom_host(ix->sbits, r); p.m = ix->m; p.sbits = ix->sbits; p.id_base = id_base;
-          p.flags = ix->flags; p.cap = cap; p.count_seen = 1;
+          p.flags = ix->flags; p.cap = cap; p.count_seen = 1; p.n = ix->n;
           R_CHECK(launch_probe(p, W, qt, s));
         }
       } else {
