@@ -29,6 +29,7 @@
 
 #define MIH_BLK 256
 #define MIH_PPT 4                       // probes per thread
+#define MIH_EPT 4u                      // bucket entries per thread and round in the verify phase
 #define MIH_PCH (MIH_BLK * MIH_PPT)     // probes per block pass
 #define MIH_QTILE 256u                  // queries resident per search tile
 #define MIH_APPROX_FACTOR 20u           // search_worker.h:14
@@ -301,60 +302,76 @@ __global__ void __launch_bounds__(MIH_BLK) mih_probe_kernel(const ProbeParams p)
   // ---- phase 3: balanced expansion of the bucket entries, gather + verify + owner rule + compaction
   const uint64_t thresh = p.st.thresh[slot];
   uint64_t* ring = p.st.ring + (uint64_t)slot * p.cap;
-  const uint32_t nwaves_iter = (total + MIH_BLK - 1) / MIH_BLK;
-  for (uint32_t it = 0; it < nwaves_iter; ++it) {
-    const uint32_t e = it * MIH_BLK + threadIdx.x;
-    bool emit = false;
-    uint64_t packed = 0;
-    if (e < total) {
-      uint32_t lo = 0, hi = nb;            // largest b with s_pref[b] <= e
+  // MIH_EPT entries per thread and round: their bucket searches, id loads and code loads are all issued before the
+  // first one is consumed (a round is a chain LDS search -> global loads -> verify; with one entry per thread the wave
+  // spends most of a big-bucket shell waiting on it)
+  constexpr uint32_t ROUND = MIH_BLK * MIH_EPT;
+  const uint32_t nrounds = (total + ROUND - 1) / ROUND;
+  uint32_t seen_acc = 0;   // wave-uniform
+  for (uint32_t it = 0; it < nrounds; ++it) {
+    uint32_t local[MIH_EPT];
+    uint64_t x[MIH_EPT][W];
+    bool live[MIH_EPT];
+#pragma unroll
+    for (uint32_t g = 0; g < MIH_EPT; ++g) {
+      const uint32_t e = it * ROUND + g * MIH_BLK + threadIdx.x;
+      live[g] = e < total;
+      const uint32_t ec = live[g] ? e : 0;   // clamp: entry 0 exists whenever total > 0
+      uint32_t lo = 0, hi = nb;               // largest b with s_pref[b] <= e
       while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (s_pref[mid] <= e) lo = mid; else hi = mid;
+        if (s_pref[mid] <= ec) lo = mid; else hi = mid;
       }
-      const uint32_t pos = s_off[lo] + (e - s_pref[lo]);
-      const uint32_t local = tv.ids[pos];
-      uint64_t x[W];
+      const uint32_t pos = s_off[lo] + (ec - s_pref[lo]);
+      local[g] = tv.ids[pos];
       if (tv.bcodes) {
 #pragma unroll
-        for (int j = 0; j < W; ++j) x[j] = tv.bcodes[(uint64_t)j * p.n + pos] ^ qw[j];
+        for (int j = 0; j < W; ++j) x[g][j] = tv.bcodes[(uint64_t)j * p.n + pos];
       } else {
 #pragma unroll
-        for (int j = 0; j < W; ++j) x[j] = p.cols[(uint64_t)j * p.stride + local] ^ qw[j];
+        for (int j = 0; j < W; ++j) x[g][j] = p.cols[(uint64_t)j * p.stride + local[g]];
       }
-      // per-substring distances come free with the full distance (compute_hamming_dist, image_tools.h:21-33)
-      uint32_t dist = 0;
-      emit = true;
-      for (uint32_t tt = 0; tt < p.m; ++tt) {
-        const uint32_t bp = tt * s;
-        uint32_t field = 0;
-#pragma unroll
-        for (int j = 0; j < W; ++j)
-          if ((uint32_t)j == (bp >> 6)) field = (uint32_t)(x[j] >> (bp & 63)) & smask;
-        const uint32_t d = __popc(field);
-        dist += d;
-        // owner rule: the item is reported by the first table holding its minimum substring distance, in the
-        // shell equal to that distance -- exactly once over the whole radius loop (replaces knn_found_).
-        bool reach = true;  // could table tt have fetched this item at shell d?  (sign-extended keys: only if top bits agree)
-        if ((p.flags & VC_FLAG_REF_SIGNEXT_KEYS) && s < 32) reach = ((field >> (s - 1)) & 1u) == 0;
-        if (tt != t && reach && (d < p.r || (d == p.r && tt < t))) emit = false;
-      }
-      packed = vc_pack(dist, p.id_base + local);
     }
-    const uint64_t emask = __ballot(emit);
-    if (emask == 0) continue;
-    if (p.count_seen && lane == 0) atomicAdd(&p.st.seen[slot], (unsigned long long)__popcll(emask));
-    const bool keep = emit && packed < thresh;
-    const uint64_t kmask = __ballot(keep);
-    if (kmask == 0) continue;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&p.st.count[slot], (uint32_t)__popcll(kmask));
-    base = __shfl(base, 0, VC_WAVE);
-    if (keep) {
-      const uint32_t pos = base + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull));
-      if (pos < p.cap) ring[pos] = packed;
+#pragma unroll
+    for (uint32_t g = 0; g < MIH_EPT; ++g) {
+      bool emit = live[g];
+      uint64_t packed = 0;
+      if (live[g]) {
+        // per-substring distances come free with the full distance (compute_hamming_dist, image_tools.h:21-33)
+        uint32_t dist = 0;
+        for (uint32_t tt = 0; tt < p.m; ++tt) {
+          const uint32_t bp = tt * s;
+          uint32_t field = 0;
+#pragma unroll
+          for (int j = 0; j < W; ++j)
+            if ((uint32_t)j == (bp >> 6)) field = (uint32_t)((x[g][j] ^ qw[j]) >> (bp & 63)) & smask;
+          const uint32_t d = __popc(field);
+          dist += d;
+          // owner rule: the item is reported by the first table holding its minimum substring distance, in the
+          // shell equal to that distance -- exactly once over the whole radius loop (replaces knn_found_).
+          bool reach = true;  // could table tt have fetched this item at shell d?  (sign-extended keys: only if top bits agree)
+          if ((p.flags & VC_FLAG_REF_SIGNEXT_KEYS) && s < 32) reach = ((field >> (s - 1)) & 1u) == 0;
+          if (tt != t && reach && (d < p.r || (d == p.r && tt < t))) emit = false;
+        }
+        packed = vc_pack(dist, p.id_base + local[g]);
+      }
+      const uint64_t emask = __ballot(emit);
+      if (emask == 0) continue;
+      seen_acc += (uint32_t)__popcll(emask);   // one atomic per wave after the loop: per-step atomics of every wave of
+                                               // a query on one counter line serialise in its memory channel
+      const bool keep = emit && packed < thresh;
+      const uint64_t kmask = __ballot(keep);
+      if (kmask == 0) continue;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&p.st.count[slot], (uint32_t)__popcll(kmask));
+      base = __shfl(base, 0, VC_WAVE);
+      if (keep) {
+        const uint32_t pos = base + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull));
+        if (pos < p.cap) ring[pos] = packed;
+      }
     }
   }
+  if (p.count_seen && lane == 0 && seen_acc) atomicAdd(&p.st.seen[slot], (unsigned long long)seen_acc);
 }
 
 // after vc_select: commit the shell for every listed slot, apply the stop rule, build the next lists
