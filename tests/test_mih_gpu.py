@@ -218,3 +218,27 @@ def test_mih_needs_index_and_rejects_stale(vc):
         e.add_synthetic(100, seed=2, kind=vc.SYNTH_CLUSTERED, n_centres=5, max_flips=2)  # invalidates the index
         with pytest.raises(vc.VcError):
             e.search_knn(q, 5, mode=vc.MODE_MIH_EXACT)
+
+
+def test_bucket_order_code_copies_change_nothing(vc, oracle, monkeypatch):
+    """<= 16-bit substrings verify their buckets from a bucket-order copy of the codes (VcTableView::bcodes): same
+    results, statistics and radius search as through the id gather (VC_MIH_BCODES=0)."""
+    n, bits, m, k = 120_000, 64, 4, 30
+    rng = np.random.default_rng(21)
+    codes = oracle.gen_codes(n, bits, 8, kind=1, n_centres=400, max_flips=6)
+    q = _near_queries(codes, 16, rng, 3)
+    got = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VC_MIH_BCODES", flag)
+        with vc.Engine(bits, capacity=n, n_tables=m) as e:
+            e.add_codes(codes)
+            e.build_index()
+            res, cnt, st = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+            rad = e.search_radius(q[:6], 7, mode=vc.MODE_MIH_EXACT)
+            got[flag] = (res.copy(), cnt.copy(), [(s.radius, s.n_sub_reads, s.n_candidates) for s in st], [r.copy() for r in rad])
+    a, b = got["0"], got["1"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    ores, ost = mo.find(q[0], k, stop_mult=4)
+    _check_contract(b[0][0, : b[1][0]], ores)
