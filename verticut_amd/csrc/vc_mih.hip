@@ -480,6 +480,7 @@ struct VcMihIndex {
   void* d_tile = nullptr;
   size_t tile_bytes = 0;
   uint32_t* d_lists = nullptr;   // 3 * MIH_QTILE + 4 counters
+  uint32_t* h_ctr = nullptr;     // pinned: the two counters the host reads back after every shell
 };
 
 #define MIH_CHECK(call)                                                                                  \
@@ -513,6 +514,7 @@ void vc_mih_free(VcMihIndex* ix) {
   (void)hipFree(ix->d_tables);
   (void)hipFree(ix->d_tile);
   (void)hipFree(ix->d_lists);
+  if (ix->h_ctr) (void)hipHostFree(ix->h_ctr);
   delete ix;
 }
 
@@ -807,7 +809,9 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       MIH_CHECK(hipMemsetAsync(d_ctr, 0, 16, s));
       const uint32_t* work = cur;
       uint32_t n_work = n_cur;
-      uint32_t h_ctr[2] = {0, 0};
+      if (!ix->h_ctr) MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 16, hipHostMallocDefault));   // pageable memory makes the 8-byte read-back a staged copy
+      uint32_t* h_ctr = ix->h_ctr;
+      h_ctr[0] = h_ctr[1] = 0;
       for (int round = 0;; ++round) {
         p.list = work;
         p.count_seen = round == 0;

@@ -644,10 +644,58 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
     while (P < fill) P <<= 1;
     for (uint32_t i = fill + threadIdx.x; i < P; i += VC_SEL_THREADS) a[i] = VC_PACK_INF;
   }
+  __shared__ uint64_t srt[VC_RANK_SORT_MAX];
+  // More than VC_RANK_SORT_MAX entries but only k wanted (an MIH shell with a few thousand candidates): cut by
+  // distance first -- histogram of the distances in LDS, smallest d whose cumulative count reaches k -- and keep the
+  // entries up to that distance; they usually fit the counting sort below (8 us) where the full bitonic network of
+  // 2048-8192 entries takes 25 us.
+  if (P > VC_RANK_SORT_MAX) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 2048; i += VC_SEL_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < P; i += VC_SEL_THREADS)
+      if (a[i] != VC_PACK_INF) atomicAdd(&hist[min((uint32_t)(a[i] >> 32), 2047u)], 1u);
+    __syncthreads();
+    if (threadIdx.x < VC_WAVE) {   // wave 0: 32 bins per lane
+      const uint32_t lane = threadIdx.x;
+      uint32_t mine = 0;
+      for (uint32_t i = 0; i < 32; ++i) mine += hist[lane * 32 + i];
+      uint32_t total;
+      uint32_t run = vc_wave_excl_scan(mine, total);
+      uint32_t cut = 0xFFFFFFFFu, upto = 0;
+      for (uint32_t i = 0; i < 32; ++i) {
+        run += hist[lane * 32 + i];
+        if (run >= k && cut == 0xFFFFFFFFu) {
+          cut = lane * 32 + i;
+          upto = run;
+        }
+      }
+      const uint32_t best = vc_wave_min(cut);
+      if (best == 0xFFFFFFFFu) {         // fewer than k entries in total: keep everything
+        if (lane == 0) { s_prefix_lo = 2047u; s_rank = total; }
+      } else if (cut == best) {          // exactly one lane holds the cut bin
+        s_prefix_lo = best;
+        s_rank = upto;
+      }
+    }
+    __syncthreads();
+    const uint32_t dcut = s_prefix_lo, kept = s_rank;
+    if (dcut < 2047u && kept <= VC_RANK_SORT_MAX) {   // (bin 2047 collects every larger distance: not a usable cut)
+      if (threadIdx.x == 0) s_fill = 0;
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < P; i += VC_SEL_THREADS) {
+        const uint64_t v = a[i];
+        if (v != VC_PACK_INF && (uint32_t)(v >> 32) <= dcut) srt[atomicAdd(&s_fill, 1u)] = v;
+      }
+      __syncthreads();
+      P = 2;
+      while (P < kept) P <<= 1;
+      for (uint32_t i = threadIdx.x; i < P; i += VC_SEL_THREADS) a[i] = i < kept ? srt[i] : VC_PACK_INF;
+    }
+  }
   // Small survivor sets (the usual case: a few hundred entries) are ordered by counting: entry i goes to slot
   // #{j : a[j] < a[i]} -- packed values are distinct -- which is P broadcast LDS reads per thread and one barrier
   // instead of the ~log^2 P barriers of the bitonic network.
-  __shared__ uint64_t srt[VC_RANK_SORT_MAX];
   const uint64_t* sorted = a;
   if (P <= VC_RANK_SORT_MAX) {
     __syncthreads();
