@@ -151,9 +151,42 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
   int rc = bind_device(e);
   if (rc == VC_OK) {
     hipError_t r = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
-    if (r == hipSuccess) r = hipMalloc((void**)&e->d_cols, e->stride * e->W * sizeof(uint64_t));
-    if (r == hipSuccess) r = hipMemsetAsync(e->d_cols, 0, e->stride * e->W * sizeof(uint64_t), e->own_stream);
+    // Column stride.  The verify kernel streams the W columns side by side, and how well the memory system keeps up
+    // depends on the distance between the columns and on where the allocation landed: at 1e9 x 128-bit codes the
+    // same kernel streams anywhere from 6.4 to 7.0 TB/s (tools/placement_probe3.py: a stride of exactly 2^30 items
+    // is always fast there, 9 * 2^27 items is always slow at 1.2e9 codes, most strides are a lottery per allocation).
+    // Nothing about the address hashing is documented, so a big multi-column database is allocated with room for a
+    // few candidate strides and each is timed with a streaming read in the verify kernel's access pattern.
+    std::vector<uint64_t> cand{e->stride};
+    const uint64_t col_min = e->stride * sizeof(uint64_t);
+    int tries = 6;
+    if (const char* t = getenv("VC_STRIDE_TRIES")) tries = std::max(1, atoi(t));   // 1 = take the first
+    if (e->W >= 2 && col_min >= (256ull << 20) && tries > 1) {
+      uint64_t p2 = VC_PAD_ITEMS;
+      while (p2 < cfg->capacity) p2 <<= 1;
+      if (p2 - e->stride <= e->stride / 12) cand.push_back(p2);                       // power of two, if it costs < 8 %
+      for (int j = 1; (int)cand.size() < tries; ++j) cand.push_back(e->stride + (uint64_t)j * 4 * VC_PAD_ITEMS);   // + j * 256 KiB
+    }
+    const uint64_t stride_max = *std::max_element(cand.begin(), cand.end());
+    const size_t col_bytes = stride_max * e->W * sizeof(uint64_t);
+    if (r == hipSuccess) r = hipMalloc((void**)&e->d_cols, col_bytes);
+    if (r == hipSuccess) r = hipMemsetAsync(e->d_cols, 0, col_bytes, e->own_stream);
     if (r == hipSuccess) r = hipStreamSynchronize(e->own_stream);
+    if (r == hipSuccess && cand.size() > 1) {
+      uint64_t* d_sink = nullptr;
+      if (hipMalloc((void**)&d_sink, 8) == hipSuccess) {
+        float best = -1.f;
+        for (uint64_t st : cand) {
+          const float ms = vc_probe_stream_ms(e->d_cols, st, e->W, cfg->capacity, d_sink, e->n_cu, e->own_stream);
+          if (getenv("VC_STRIDE_TRACE")) fprintf(stderr, "[vc stride] %llu items: %.3f ms\n", (unsigned long long)st, ms);
+          if (ms > 0 && (best < 0 || ms < best)) {
+            best = ms;
+            e->stride = st;
+          }
+        }
+        (void)hipFree(d_sink);
+      }
+    }
     if (r != hipSuccess) rc = fail(nullptr, r == hipErrorOutOfMemory ? VC_ERR_NOMEM : VC_ERR_HIP, "engine setup: %s", hipGetErrorString(r));
   } else {
     g_create_err = e->err;

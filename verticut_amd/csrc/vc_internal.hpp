@@ -12,6 +12,8 @@ struct VcScanShape {
 };
 VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes);
 
+float vc_probe_stream_ms(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t items, uint64_t* d_sink, uint32_t n_cu,
+                         hipStream_t s);
 hipError_t vc_launch_fill_synth(uint64_t* cols, uint64_t stride, uint32_t W, uint64_t first_local, uint64_t n,
                                 uint64_t first_gid, uint64_t seed, uint32_t kind, uint32_t n_centres,
                                 uint32_t max_flips, hipStream_t s);

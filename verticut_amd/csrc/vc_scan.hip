@@ -43,6 +43,29 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // data-movement kernels
 // ------------------------------------------------------------------------------------------
+// Streaming-read probe in the verify kernel's access pattern: persistent blocks walk chunks of 2048 items grid-strided
+// and read every column of a chunk (16 B per lane, non-temporal).  vc_create times it for a few candidate column
+// strides (see there).
+template <int W>
+__global__ void __launch_bounds__(256) vc_stream_probe_kernel(const uint64_t* __restrict__ cols, uint64_t stride,
+                                                              uint64_t nchunks, uint64_t* __restrict__ sink) {
+  uint64_t acc = 0;
+  for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    vc_u64x2 v[4][W];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        v[u][j] = __builtin_nontemporal_load(
+            reinterpret_cast<const vc_u64x2*>(cols + (uint64_t)j * stride + c * 2048 + (uint64_t)u * 512 + 2 * threadIdx.x));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc += v[u][j].x ^ v[u][j].y;
+  }
+  if (acc == 0x9E3779B97F4A7C15ull) *sink = acc;   // keeps the loads alive; never true on the zero-filled buffer
+}
+
 __global__ void __launch_bounds__(256) vc_fill_synth_kernel(uint64_t* __restrict__ cols, uint64_t stride, uint32_t W,
                                                             uint64_t first_local, uint64_t n, uint64_t first_gid,
                                                             uint64_t seed, uint32_t kind, uint32_t n_centres,
@@ -788,6 +811,32 @@ VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes) {
     }
   }
   return sh;
+}
+
+// milliseconds of the fastest of three timed passes (after one warm-up pass) of the stream probe, < 0 on error
+float vc_probe_stream_ms(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t items, uint64_t* d_sink, uint32_t n_cu,
+                         hipStream_t s) {
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess) return -1.f;
+  if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return -1.f; }
+  const uint64_t nchunks = items / 2048;
+  float best = -1.f;
+  for (int rep = 0; rep < 4 && nchunks; ++rep) {
+    (void)hipEventRecord(a, s);
+    switch (W) {
+      case 2: hipLaunchKernelGGL((vc_stream_probe_kernel<2>), dim3(n_cu * 4), dim3(256), 0, s, cols, stride, nchunks, d_sink); break;
+      case 4: hipLaunchKernelGGL((vc_stream_probe_kernel<4>), dim3(n_cu * 4), dim3(256), 0, s, cols, stride, nchunks, d_sink); break;
+      case 8: hipLaunchKernelGGL((vc_stream_probe_kernel<8>), dim3(n_cu * 4), dim3(256), 0, s, cols, stride, nchunks, d_sink); break;
+      default: (void)hipEventDestroy(a); (void)hipEventDestroy(b); return -1.f;
+    }
+    (void)hipEventRecord(b, s);
+    float ms = 0;
+    if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) { best = -1.f; break; }
+    if (rep && (best < 0 || ms < best)) best = ms;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return best;
 }
 
 hipError_t vc_launch_fill_synth(uint64_t* cols, uint64_t stride, uint32_t W, uint64_t first_local, uint64_t n,
