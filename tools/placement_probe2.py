@@ -1,30 +1,29 @@
-"""Dev tool: does the allocation lottery of the streaming rate need two concurrent column streams?  Engines with one
-64-bit column of 2e9 codes (16 GB, one stream) and with two columns of 1e9 128-bit codes (16 GB, two streams 8 GB apart)
-alternate in one process; qt = 1 scan time of each."""
+"""Dev tool: single-column (64-bit) databases: does the allocation size decide the streaming rate?  2e9 codes in engines
+created with capacity 2e9 (16.0e9 bytes) and with capacity 2^31 (16 GiB exactly), interleaved in one process; GB/s."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from verticut_amd import engine as vc
 
+n = 2 * 10**9
 rng = np.random.default_rng(0)
+q = rng.integers(0, 256, size=(8, 8), dtype=np.uint8)
 engines = []
 for i in range(8):
-    bits, n = ((64, 2 * 10**9) if i % 2 == 0 else (128, 10**9))
-    e = vc.Engine(bits, capacity=n, query_tile=8)
+    cap = n if i % 2 == 0 else 1 << 31
+    e = vc.Engine(64, capacity=cap, query_tile=8)
     e.add_synthetic(n, seed=34)
-    engines.append((bits, n, e))
+    engines.append((cap, e))
 
-def sample(e, q, reps=12):
+def rate(e, qq):
     for _ in range(3):
-        e.search_knn(q, 100)
+        e.search_knn(qq, 100)
     e.timing()
-    for _ in range(reps):
-        e.search_knn(q, 100)
+    for _ in range(10):
+        e.search_knn(qq, 100)
     t = e.timing()
-    return t.scan_ms / t.scan_launches
+    return n * 8 / (t.scan_ms / t.scan_launches) / 1e6
 
-for rnd in range(2):
-    for bits in (64, 128):
-        q = rng.integers(0, 256, size=(1, bits // 8), dtype=np.uint8)
-        print("round %d, %3d-bit (%d column%s), qt=1: " % (rnd, bits, bits // 64, "s" if bits > 64 else "") +
-              "  ".join("%.3f" % sample(e, q) for b, n, e in engines if b == bits), flush=True)
+for qt in (1, 8):
+    for cap in (n, 1 << 31):
+        print("qt=%d capacity %10d: GB/s " % (qt, cap) + "  ".join("%.0f" % rate(e, q[:qt]) for c, e in engines if c == cap), flush=True)
