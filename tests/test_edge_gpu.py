@@ -177,3 +177,38 @@ def test_device_api_is_ordered_on_the_callers_stream(vc):
         again, _ = e.search_knn(q1, k)
         torch.cuda.synchronize()
         assert np.array_equal(again, ref1) and np.array_equal(out.cpu().numpy().view(np.uint64), ref2)
+
+
+def test_results_do_not_depend_on_the_column_stride(vc, oracle, monkeypatch):
+    """vc_create may pad the column stride (it times candidate strides for big databases): every path -- ingest,
+    synthetic fill, get_code, linear and MIH search, radius search, code file save -- must honour whatever stride was
+    chosen.  VC_STRIDE_FORCE picks odd ones for a small database."""
+    n, bits, k = 70_000, 128, 25
+    codes = oracle.gen_codes(n, bits, 4, kind=1, n_centres=150, max_flips=7)
+    rng = np.random.default_rng(2)
+    q = codes[rng.integers(0, n, size=10)].copy()
+    q[:, 2] ^= 0x09
+    ref = None
+    for force in (None, "81920", "131072", "212992"):
+        if force is None:
+            monkeypatch.delenv("VC_STRIDE_FORCE", raising=False)
+        else:
+            monkeypatch.setenv("VC_STRIDE_FORCE", force)
+        with vc.Engine(bits, capacity=n, n_tables=4, query_tile=4) as e:
+            if force == "131072":
+                e.add_synthetic(n, seed=4, kind=1, n_centres=150, max_flips=7)
+            else:
+                e.add_codes(codes)
+            assert np.array_equal(e.get_code(n - 1), codes[n - 1]) and np.array_equal(e.get_code(12345), codes[12345])
+            lin, lcnt = e.search_knn(q, k)
+            e.build_index()
+            mih, mcnt = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT)
+            rad = e.search_radius(q[:3], 9, mode=vc.MODE_MIH_EXACT)
+            got = (lin.copy(), lcnt.copy(), mih.copy(), mcnt.copy(), [r.copy() for r in rad])
+        if ref is None:
+            ref = got
+            for i in range(len(q)):
+                assert np.array_equal(lin[i, : lcnt[i]], oracle.linear_knn(codes, q[i], k))
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(got[:4], ref[:4]))
+            assert all(np.array_equal(a, b) for a, b in zip(got[4], ref[4]))

@@ -167,6 +167,13 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
       if (p2 - e->stride <= e->stride / 12) cand.push_back(p2);                       // power of two, if it costs < 8 %
       for (int j = 1; (int)cand.size() < tries; ++j) cand.push_back(e->stride + (uint64_t)j * 4 * VC_PAD_ITEMS);   // + j * 256 KiB
     }
+    if (const char* f = getenv("VC_STRIDE_FORCE")) {   // test knob: a given stride (items, multiple of 8192, >= capacity)
+      const uint64_t fs = strtoull(f, nullptr, 10);
+      if (fs >= e->stride && fs % VC_PAD_ITEMS == 0) {
+        cand.assign(1, fs);
+        e->stride = fs;
+      }
+    }
     const uint64_t stride_max = *std::max_element(cand.begin(), cand.end());
     const size_t col_bytes = stride_max * e->W * sizeof(uint64_t);
     if (r == hipSuccess) r = hipMalloc((void**)&e->d_cols, col_bytes);
