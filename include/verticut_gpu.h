@@ -169,8 +169,10 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
  * d_queries: nq*bits/8 bytes; d_out: nq*k uint64, ascending, padded with UINT64_MAX; d_counts: nq uint32.
  * Asynchronous on `stream` and ordered like any other work enqueued there when mode == VC_MODE_LINEAR; other
  * modes synchronise that stream.
- * LINEAR cannot recover from a candidate-ring overflow without a host round trip: such a query reports
- * d_counts[i] == UINT32_MAX (its row is then only an upper bound) and should be re-run through vc_search_knn. */
+ * A candidate-ring overflow (more than cand_cap items at or below the k-th distance: duplicate-heavy data,
+ * linear_search.cc:113-117 mentions 250 000-entry buckets) is recovered exactly ON THE DEVICE in the same stream
+ * (radix select over the position of the tied items), so a LINEAR row is always exact.  Only if that
+ * recovery gives up (see vc_device_status) a query reports d_counts[i] == UINT32_MAX with an upper-bound row. */
 int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode,
                       uint64_t* d_out, uint32_t* d_counts, void* stream);
 /* All items within full Hamming distance <= radius of each query (BASELINE config 2; built from
@@ -179,6 +181,12 @@ int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t
  * ascending packed.  VC_ERR_CAPACITY (with out_offsets filled with the needed counts) if out_cap is too small. */
 int vc_search_radius(vc_engine* e, const void* queries, uint32_t nq, uint32_t radius, uint32_t mode,
                      uint64_t* out, uint64_t out_cap, uint64_t* out_offsets);
+
+/* Sticky status of the asynchronous device path: *n_gave_up = calls since the previous vc_device_status() in which the
+ * device-side ring-overflow recovery could not complete (its grid never met: the GPU was held by other kernels for
+ * seconds); the affected queries kept d_counts[i] == UINT32_MAX.  0 in normal operation.  Synchronises the stream.
+ * replaces: nothing in the reference (its find() is synchronous, search_worker.cc:65-89). */
+int vc_device_status(vc_engine* e, uint32_t* n_gave_up);
 
 /* ---- multi-GPU merge ---------------------------------------------------------------------
  * replaces: mpi_coordinator::gather_vectors + master-side heap (mpi_coordinator.cc:34-69,

@@ -111,3 +111,56 @@ def test_config5_shape_256bit_4096_query_tile(vc):
         assert tb.scan_launches == 1 and ts.scan_launches == 256
         assert np.array_equal(a, b) and np.array_equal(ca, cb)
         _check_rows(big, q[:3], a[:3], ca[:3])
+
+
+def test_config5_tile_4096_against_the_oracle(vc, oracle):
+    """BASELINE configs[4]'s query tile (4096 x 256-bit queries in LDS, 512-thread blocks, one pass over the database)
+    against the CPU oracle itself -- not against another HIP tile: 512 of the 4096 rows, uniform and near-duplicate
+    queries (linear_search.cc:44-57)."""
+    n, bits, k, nq = 250_000, 256, 100, 4096
+    rng = np.random.default_rng(55)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=900, max_flips=20)
+    q = rng.integers(0, 256, size=(nq, bits // 8), dtype=np.uint8)
+    near = rng.choice(nq, size=1024, replace=False)
+    q[near] = codes[rng.integers(0, n, size=1024)]
+    for i in near[::2]:
+        q[i] = _flip(q[i], rng.choice(bits, size=int(rng.integers(1, 30)), replace=False), rng)
+    with vc.Engine(bits, capacity=n, query_tile=4096) as e:
+        e.add_synthetic(n, seed=34, kind=1, n_centres=900, max_flips=20)
+        rows, cnt = e.search_knn(q, k)
+        t = e.timing()
+        assert t.scan_launches == 1 and t.scan_bytes == n * 32      # ONE pass for all 4096 queries
+        assert np.all(cnt == k)
+        check = np.concatenate([[0, 1, nq - 1], near[:253], rng.choice(nq, size=256, replace=False)])
+        for i in check:
+            assert np.array_equal(rows[i], oracle.linear_knn(codes, q[i], k)), i
+
+
+def test_config5_per_gpu_share_5e8_codes_4096_queries(vc):
+    """configs[4] at the size one of its 8 GPUs holds (5e8 x 256-bit codes = 16 GB, 4096 queries per pass), through
+    size-independent properties: planted neighbours come back first at their exact distance, rows ascend, reported
+    distances are what the stored codes say, and the 4096-query tile agrees with the 8-query tile of a second engine."""
+    n, bits, k, nq = 500_000_000, 256, 100, 4096
+    rng = np.random.default_rng(6)
+    q = rng.integers(0, 256, size=(nq, bits // 8), dtype=np.uint8)
+    with vc.Engine(bits, capacity=n, query_tile=4096) as e:
+        e.add_synthetic(n, seed=34)
+        slots = [0, 1, 511, 512, 2047, 4095, 77, 3000]
+        plant = [int(x) for x in rng.integers(0, n, size=len(slots))]
+        nflip = [0, 1, 2, 5, 9, 17, 33, 60]
+        for s, g, f in zip(slots, plant, nflip):
+            q[s] = _flip(e.get_code(g), rng.choice(bits, size=f, replace=False), rng)
+        rows, cnt = e.search_knn(q, k)
+        t = e.timing()
+        assert t.scan_launches == 1 and t.scan_bytes == n * 32
+        assert np.all(cnt == k)
+        assert np.all(rows[:, 1:] > rows[:, :-1])
+        for s, g, f in zip(slots, plant, nflip):
+            assert int(rows[s, 0] & MASK) == g and int(rows[s, 0] >> SH) == f
+        _check_rows(e, q[slots[:4]], rows[slots[:4]], cnt[slots[:4]])
+        _check_rows(e, q[[5, 2500]], rows[[5, 2500]], cnt[[5, 2500]])
+    sub = slots + [5, 2500, 4000]
+    with vc.Engine(bits, capacity=n, query_tile=8) as e8:
+        e8.add_synthetic(n, seed=34)
+        r8, c8 = e8.search_knn(q[sub], k)
+        assert np.array_equal(r8, rows[sub]) and np.all(c8 == k)

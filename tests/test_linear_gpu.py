@@ -111,9 +111,12 @@ def test_second_bootstrap_stage(vc, oracle, monkeypatch):
         assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp)
 
 
-def test_ring_overflow_recovery(vc, oracle):
-    """more items at the k-th distance than the candidate ring holds: the scan is repeated with the packed bound
-    of what did fit until nothing overflows; the answer is still the k smallest (dist, id)."""
+@pytest.mark.parametrize("device_recover", ["1", "0"])
+def test_ring_overflow_recovery(vc, oracle, monkeypatch, device_recover):
+    """more items at the k-th distance than the candidate ring holds: recovered on the device by a radix select over
+    the position of the tied items (default), or -- VC_DEVICE_RECOVER=0, the fallback -- by repeating the scan with
+    the packed bound of what did fit until nothing overflows; the answer is still the k smallest (dist, id)."""
+    monkeypatch.setenv("VC_DEVICE_RECOVER", device_recover)
     rng = np.random.default_rng(12)
     base = rng.integers(0, 256, size=(10, 16), dtype=np.uint8)
     codes = np.repeat(base, 3000, axis=0)          # 30000 items, 3000 copies of each
@@ -127,10 +130,12 @@ def test_ring_overflow_recovery(vc, oracle):
         assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp)
 
 
-def test_ring_overflow_with_tiny_ring_and_loose_early_entries(vc, oracle):
+@pytest.mark.parametrize("device_recover", ["1", "0"])
+def test_ring_overflow_with_tiny_ring_and_loose_early_entries(vc, oracle, monkeypatch, device_recover):
     """k = 1, ring of 4: the entries that fit arrive under the loose start threshold while thousands of duplicates
     (counted in the histogram, not stored) pull the final threshold below all of them -- the recovery bound must
     still come from what fitted (regression: the select pre-filter used to empty such a row)."""
+    monkeypatch.setenv("VC_DEVICE_RECOVER", device_recover)
     n = 400_000
     codes = oracle.gen_codes(n, 256, 900, kind=1, n_centres=7, max_flips=0)    # 7 distinct codes, ~57 K copies each
     q = codes[[3, 1000, 77777, 399_999]].copy()
@@ -141,6 +146,60 @@ def test_ring_overflow_with_tiny_ring_and_loose_early_entries(vc, oracle):
             got, cnt = e.search_knn(q, k)
             exp, ecnt = _expect(oracle, codes, q, k)
             assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp)
+
+
+def _dev_search(e, q, k):
+    import torch
+    nq = q.shape[0]
+    dq = torch.from_numpy(q).cuda()
+    out = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+    cnt = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+    e.search_knn_dev(dq.data_ptr(), nq, k, out.data_ptr(), cnt.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(np.uint64), cnt.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("cand_cap,k", [(4, 1), (4, 3), (64, 16), (256, 100), (1024, 256)])
+def test_device_api_ring_overflow_is_exact(vc, oracle, cand_cap, k):
+    """vc_search_knn_dev on a duplicate-heavy shard (7 distinct codes x 57 K copies) with rings of 4..1024 entries:
+    every row overflows its ring and is recomputed exactly on the device, asynchronously (no UINT32_MAX marker left,
+    counts == k), for 12 queries = three tiles, two recovery rounds (linear_search.cc:44-57 keeps the lowest ids)."""
+    n = 400_000
+    codes = oracle.gen_codes(n, 256, 900, kind=1, n_centres=7, max_flips=0)
+    rng = np.random.default_rng(k)
+    q = codes[rng.integers(0, n, size=12)].copy()
+    q[1, 0] ^= 1                                   # ties at distance 1
+    q[5, 7] ^= 0x81                                # ties at distance 2
+    q[11] = rng.integers(0, 256, size=32, dtype=np.uint8)   # far from everything: ties at some large distance
+    with vc.Engine(256, capacity=n, query_tile=4, cand_cap=cand_cap, id_base=1000) as e:
+        e.add_codes(codes)
+        got, cnt = _dev_search(e, q, k)
+        exp, ecnt = _expect(oracle, codes, q, k, id_base=1000)
+        assert np.array_equal(cnt, ecnt), cnt
+        assert np.array_equal(got, exp)
+        assert e.device_status() == 0
+        host, hcnt = e.search_knn(q, k)            # the host API takes the same device path
+        assert np.array_equal(host, exp) and np.array_equal(hcnt, ecnt)
+
+
+def test_device_recovery_three_position_levels(vc, oracle):
+    """5 M codes = 23 position bits = three radix levels (11 + 11 + 1 bits) of the tie select; mixed batch in which
+    only some queries overflow"""
+    n, bits = 5_000_000, 128
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 256, size=(3, bits // 8), dtype=np.uint8)
+    codes = base[rng.integers(0, 3, size=n)]
+    uni = oracle.gen_codes(1000, bits, 5)
+    codes[rng.integers(0, n, size=1000)] = uni     # a sprinkle of distinct codes
+    q = np.stack([base[0], base[2], uni[3], base[1]])
+    q[3, 2] ^= 0x18
+    for cand_cap, k in ((16, 5), (4096, 1000)):
+        with vc.Engine(bits, capacity=n, cand_cap=cand_cap, query_tile=8) as e:
+            e.add_codes(codes)
+            got, cnt = _dev_search(e, q, k)
+            exp, ecnt = _expect(oracle, codes, q, k)
+            assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp)
+            assert e.device_status() == 0
 
 
 def test_timing_reports_scan(vc):

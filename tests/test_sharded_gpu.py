@@ -72,6 +72,48 @@ def _worker(rank, world, port, total_n, bits, k, ret):
     dist.destroy_process_group()
 
 
+def _worker_overflow(rank, world, port, total_n, bits, k, cand_cap, ret):
+    """duplicate-heavy shards whose candidate rings overflow: the asynchronous device path must hand exact per-shard
+    top-k to the exchange (round-1 hole: the overflow marker was dropped and the merged row was silently wrong)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import vc_oracle as vo
+    from verticut_amd.sharded import ShardedSearch
+    full = vo.gen_codes(total_n, bits, 900, 1, 7, 0)          # 7 distinct codes x ~57 K copies
+    ss = ShardedSearch(bits, total_n, rank=rank, world=world, device=0, cand_cap=cand_cap, query_tile=4)
+    ss.add_codes_global(full)
+    rng = np.random.default_rng(3)
+    q = full[rng.integers(0, total_n, size=9)].copy()
+    q[2, 1] ^= 0x40
+    q[8] = rng.integers(0, 256, size=bits // 8, dtype=np.uint8)
+    ok = True
+    for bucket in (1, 3):
+        sb = ShardedSearch(bits, total_n, rank=rank, world=world, device=0, bucket=bucket, backend=ss.backend)
+        out, cnt = sb.search(torch.from_numpy(q).cuda(), k)
+        sb.flush()
+        torch.cuda.synchronize()
+        exp = np.stack([vo.linear_knn(full, q[i], k) for i in range(len(q))])
+        ok = ok and bool(np.array_equal(out.cpu().numpy().view(np.uint64), exp)) and bool(np.all(cnt.cpu().numpy() == k))
+        ok = ok and sb.unrecovered() == 0
+    ret[rank] = ok
+    ss.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cand_cap,k", [(4, 1), (256, 100)])
+def test_two_ranks_duplicate_heavy_shards_overflow(cand_cap, k):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_overflow, args=(2, port, 400_000, 256, k, cand_cap, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_two_ranks_one_gpu_equals_unsharded():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

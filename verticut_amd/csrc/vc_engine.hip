@@ -29,6 +29,8 @@ struct vc_engine {
   uint64_t* d_ring = nullptr;   size_t ring_bytes = 0;    // per tile: [qt][cap]
   uint64_t* d_out = nullptr;    size_t out_bytes = 0;     // [nq][k]
   uint32_t* d_cnt = nullptr;    size_t cnt_bytes = 0;     // [nq] result counts | [nq] raw ring counts
+  uint32_t* d_rec = nullptr;                              // scratch of the device-side ring-overflow recovery (zero at first use)
+  VcKnobs knobs;                                          // environment knobs, read once at vc_create
 
   // timing: event pairs recorded since the last vc_get_timing (calls: whole search calls, scans: verify launches)
   std::vector<hipEvent_t> ev_pool;
@@ -79,6 +81,23 @@ static int grow(vc_engine* e, T** p, size_t* have, size_t need) {
   VC_HIP(e, hipMalloc((void**)p, need));
   *have = need;
   return VC_OK;
+}
+
+// environment knobs (developer / test switches): read here, once per engine, never on a launch path
+static void read_knobs(VcKnobs* k) {
+  if (const char* w = getenv("VC_SCAN_WRAP")) k->scan_wrap = (uint32_t)atoi(w);
+  if (const char* w = getenv("VC_SCAN_DIAG")) k->scan_diag = (uint32_t)atoi(w);
+  if (const char* s2 = getenv("VC_SAMPLE2")) { k->sample2_set = true; k->sample2 = strtoull(s2, nullptr, 10); }
+  if (const char* sh = getenv("VC_SCAN_SHAPE")) {
+    int u = 0, b = 0, d = 2;
+    if (sscanf(sh, "%d,%d,%d", &u, &b, &d) >= 1) { k->shape_set = true; k->shape_u = u; k->shape_blk = b; k->shape_db = d; }
+  }
+  if (const char* g = getenv("VC_SAMPLE_BLOCKS_PER_CU")) k->sample_blocks_per_cu = (uint32_t)std::max(1, atoi(g));
+  k->recover_trace = getenv("VC_RECOVER_TRACE") != nullptr;
+  k->mih_trace = getenv("VC_MIH_TRACE") != nullptr;
+  if (const char* r = getenv("VC_DEVICE_RECOVER")) k->device_recover = atoi(r) != 0;
+  if (const char* v = getenv("VC_MIH_BCODES")) k->mih_bcodes = atoi(v) != 0;
+  if (const char* v = getenv("VC_MIH_HOST_LOOP")) k->mih_host_loop = atoi(v);
 }
 
 static int bind_device(vc_engine* e) {
@@ -139,6 +158,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
   e->m = cfg->n_tables;
   e->sbits = sbits;
   e->n_cu = (uint32_t)prop.multiProcessorCount;
+  read_knobs(&e->knobs);
   e->cap = cfg->cand_cap ? cfg->cand_cap : 65536u;
   // queries verified per database pass: 8 keeps the pass on the HBM side of the roofline (bench), larger tiles trade
   // bandwidth efficiency for queries/s until the popcount VALU ceiling; default for big batches: 32
@@ -158,6 +178,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
     // Nothing about the address hashing is documented, so a big multi-column database is allocated with room for a
     // few candidate strides and each is timed with a streaming read in the verify kernel's access pattern.
     std::vector<uint64_t> cand{e->stride};
+    const bool stride_trace = getenv("VC_STRIDE_TRACE") != nullptr;
     const uint64_t col_min = e->stride * sizeof(uint64_t);
     int tries = 6;
     if (const char* t = getenv("VC_STRIDE_TRIES")) tries = std::max(1, atoi(t));   // 1 = take the first
@@ -185,7 +206,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
         float best = -1.f;
         for (uint64_t st : cand) {
           const float ms = vc_probe_stream_ms(e->d_cols, st, e->W, cfg->capacity, d_sink, e->n_cu, e->own_stream);
-          if (getenv("VC_STRIDE_TRACE")) fprintf(stderr, "[vc stride] %llu items: %.3f ms\n", (unsigned long long)st, ms);
+          if (stride_trace) fprintf(stderr, "[vc stride] %llu items: %.3f ms\n", (unsigned long long)st, ms);
           if (ms > 0 && (best < 0 || ms < best)) {
             best = ms;
             e->stride = st;
@@ -220,6 +241,7 @@ int vc_destroy(vc_engine* e) {
   (void)hipFree(e->d_ring);
   (void)hipFree(e->d_out);
   (void)hipFree(e->d_cnt);
+  (void)hipFree(e->d_rec);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->last_call) (void)hipEventDestroy(e->last_call);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -452,6 +474,11 @@ static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
   int rc;
   if ((rc = grow(e, &e->d_state, &e->state_bytes, b->state_words * 4))) return rc;
   if ((rc = grow(e, &e->d_ring, &e->ring_bytes, (size_t)b->GQ * b->cap * 8))) return rc;
+  if (!e->d_rec && e->knobs.device_recover) {
+    const size_t bytes = vc_recover_scratch_words() * 4;
+    VC_HIP(e, hipMalloc((void**)&e->d_rec, bytes));
+    VC_HIP(e, hipMemsetAsync(e->d_rec, 0, bytes, e->stream));
+  }
   b->d_count = e->d_state;
   b->d_hist = b->d_count + (size_t)b->GQ * VC_QUERY_LINE_WORDS;
   b->d_shist = b->d_hist + (size_t)b->GQ * b->hs;
@@ -463,7 +490,7 @@ static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
 // one verify launch for a tile whose tau is already set (the tile's state starts at query t0 of the group); d_limit may be null
 static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint32_t qt, uint32_t k, const uint64_t* d_limit,
                      uint32_t t0 = 0) {
-  const VcScanShape sh = vc_scan_pick_shape(e->W, qt, nullptr);
+  const VcScanShape sh = vc_scan_pick_shape(e->W, qt, nullptr, &e->knobs);
   VcScanParams p{};
   p.cols = e->d_cols;
   p.stride = e->stride;
@@ -481,12 +508,12 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
   p.hist = b.d_hist + (size_t)t0 * b.hs;
   p.buf = e->d_ring + (size_t)t0 * b.cap;
   p.limit = d_limit;
-  if (const char* w = getenv("VC_SCAN_WRAP")) p.wrap = (uint32_t)atoi(w);   // diagnostic, results are wrong by design
-  if (const char* w = getenv("VC_SCAN_DIAG")) p.diag = (uint32_t)atoi(w);   // diagnostic, results are wrong by design
+  p.wrap = e->knobs.scan_wrap;   // diagnostic build only, results are wrong by design
+  p.diag = e->knobs.scan_diag;
   hipEvent_t a, bb;
   ev_pair(e, &a, &bb);
   if (a) VC_HIP(e, hipEventRecord(a, e->stream));
-  VC_HIP(e, vc_launch_scan(p, e->W, e->n_cu, e->scan_blocks, e->stream));
+  VC_HIP(e, vc_launch_scan(p, e->W, e->n_cu, e->scan_blocks, &e->knobs, e->stream));
   if (a) {
     VC_HIP(e, hipEventRecord(bb, e->stream));
     e->ev_scans.emplace_back(a, bb);
@@ -512,21 +539,28 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
   uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(262144, 64ull * k));
   uint64_t sample2 = std::min<uint64_t>(e->n / 16, sample * 8);   // 2.1 M codes at k = 100
   if (sample2 < 4 * sample) sample2 = 0;
-  if (const char* s2 = getenv("VC_SAMPLE2")) sample2 = std::min<uint64_t>(e->n, strtoull(s2, nullptr, 10));   // dev/test knob
+  if (e->knobs.sample2_set) sample2 = std::min<uint64_t>(e->n, e->knobs.sample2);   // dev/test knob VC_SAMPLE2
   if (sample2) sample = std::min<uint64_t>(sample, std::max<uint64_t>(65536, 64ull * k));   // stage 1 only has to seed stage 2
   for (uint32_t g0 = 0; g0 < nq; g0 += b.GQ) {
     const uint32_t gq = std::min(b.GQ, nq - g0);
     const uint64_t* dg = d_q + (size_t)g0 * e->W;
     VC_HIP(e, hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
     VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dg, gq, b.d_shist, b.hs, k, e->bits, b.d_tau, VC_QUERY_LINE_WORDS, false,
-                                    e->n_cu, e->stream));
+                                    e->n_cu, e->knobs.sample_blocks_per_cu, e->stream));
     if (sample2)
       VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample2, dg, gq, b.d_shist2, b.hs, k, e->bits, b.d_tau, VC_QUERY_LINE_WORDS, true,
-                                      e->n_cu, e->stream));
+                                      e->n_cu, e->knobs.sample_blocks_per_cu, e->stream));
     for (uint32_t t0 = 0; t0 < gq; t0 += b.QT)
       if ((rc = scan_tile(e, b, dg + (size_t)t0 * e->W, std::min(b.QT, gq - t0), k, nullptr, t0))) return rc;
     VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, VC_QUERY_LINE_WORDS, gq, k, d_out + (size_t)g0 * k,
                                     d_cnt + g0, e->stream));
+    // rows whose ring overflowed (count reported as UINT32_MAX) are recomputed exactly on the device: a no-op launch otherwise
+    if (e->knobs.device_recover)
+      for (uint32_t c0 = 0; c0 < gq; c0 += 64)   // one launch serves 64 queries (a group is larger only when one tile is: query_tile > 64)
+        VC_HIP(e, vc_launch_recover(e->d_cols, e->stride, e->n, e->W, e->cfg.id_base, e->bits, dg + (size_t)c0 * e->W, std::min(64u, gq - c0), k,
+                                    e->d_ring + (size_t)c0 * b.cap, b.cap, b.d_count + (size_t)c0 * VC_QUERY_LINE_WORDS,
+                                    b.d_hist + (size_t)c0 * b.hs, b.hs, VC_QUERY_LINE_WORDS, e->d_rec, d_out + (size_t)(g0 + c0) * k,
+                                    d_cnt + g0 + c0, e->n_cu, e->stream));
     if (d_raw)   // one counter per 128-byte line -> dense
       VC_HIP(e, hipMemcpy2DAsync(d_raw + g0, 4, b.d_count, VC_QUERY_LINE_WORDS * 4, 4, gq, hipMemcpyDeviceToDevice, e->stream));
   }
@@ -568,7 +602,7 @@ static int linear_recover(vc_engine* e, const uint64_t* d_q, uint32_t k, const s
   };
   std::vector<Rec> todo;
   for (uint32_t q : over) todo.push_back(Rec{q, 0, out[(size_t)q * k + k - 1], false, 0, false, 0});
-  const bool trace = getenv("VC_RECOVER_TRACE") != nullptr;   // dev knob
+  const bool trace = e->knobs.recover_trace;   // dev knob VC_RECOVER_TRACE
   for (int round = 0; !todo.empty(); ++round) {
     if (round > 200) { cleanup(); return fail(e, VC_ERR_CAPACITY, "ring overflow recovery did not converge"); }
     std::vector<Rec> next;
@@ -684,10 +718,11 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
   VC_HIP(e, hipMemcpyAsync(cnt.data(), e->d_cnt, (mode == VC_MODE_LINEAR ? 2 : 1) * (size_t)nq * 4, hipMemcpyDeviceToHost, e->stream));
   VC_HIP(e, hipStreamSynchronize(e->stream));
   if (mode == VC_MODE_LINEAR) {
-    const uint32_t cap = std::max(e->cap, 4 * k);
+    // a row still flagged here overflowed its ring and was not recomputed on the device (VC_DEVICE_RECOVER=0, or the
+    // recovery grid gave up): host-driven fallback
     std::vector<uint32_t> over;
     for (uint32_t i = 0; i < nq; ++i)
-      if (cnt[nq + i] > cap) over.push_back(i);
+      if (cnt[i] == 0xFFFFFFFFu) over.push_back(i);
     if (!over.empty() && (rc = linear_recover(e, e->d_q, k, over, out, cnt.data()))) return rc;
   }
   for (uint32_t i = 0; i < nq; ++i) {
@@ -703,6 +738,19 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
       stats[i].n_results = cnt[i];
     }
   }
+  return VC_OK;
+}
+
+int vc_device_status(vc_engine* e, uint32_t* n_gave_up) {
+  if (!e || !n_gave_up) return VC_ERR_INVALID;
+  *n_gave_up = 0;
+  if (!e->d_rec) return VC_OK;
+  int rc = bind_device(e);
+  if (rc) return rc;
+  uint32_t* d_flag = e->d_rec + vc_recover_scratch_words() - 32;
+  VC_HIP(e, hipMemcpyAsync(n_gave_up, d_flag, 4, hipMemcpyDeviceToHost, e->stream));
+  VC_HIP(e, hipMemsetAsync(d_flag, 0, 4, e->stream));
+  VC_HIP(e, hipStreamSynchronize(e->stream));
   return VC_OK;
 }
 
@@ -722,7 +770,7 @@ int vc_build_index(vc_engine* e) {
   if (rc) return rc;
   if (e->mih) { vc_mih_free(e->mih); e->mih = nullptr; }
   return vc_mih_build(&e->mih, e->d_cols, e->stride, e->n, e->W, e->m, e->sbits, e->cfg.id_base, e->cfg.flags, e->n_cu,
-                      e->cap, e->stream, &e->err);
+                      e->cap, e->knobs, e->stream, &e->err);
 }
 
 int vc_get_bucket(vc_engine* e, uint32_t table, uint32_t index, uint32_t* ids, void* codes, uint32_t cap, uint32_t* n) {

@@ -2,6 +2,21 @@
 #pragma once
 #include "vc_common.hpp"
 
+// Developer / test knobs from the environment, read ONCE per engine at vc_create (never on a launch path).
+struct VcKnobs {
+  uint32_t scan_wrap = 0, scan_diag = 0;      // VC_SCAN_WRAP / VC_SCAN_DIAG (diagnostic build only; results wrong by design)
+  bool sample2_set = false;                   // VC_SAMPLE2: size of the second bootstrap stage
+  uint64_t sample2 = 0;
+  bool shape_set = false;                     // VC_SCAN_SHAPE "U,BLK,DB"
+  int shape_u = 0, shape_blk = 0, shape_db = 0;
+  uint32_t sample_blocks_per_cu = 8;          // VC_SAMPLE_BLOCKS_PER_CU
+  bool recover_trace = false;                 // VC_RECOVER_TRACE
+  bool mih_trace = false;                     // VC_MIH_TRACE
+  bool device_recover = true;                 // VC_DEVICE_RECOVER=0: ring overflow handled by the host-driven fallback only
+  int mih_bcodes = -1;                        // VC_MIH_BCODES: -1 auto, 0 / 1 forced
+  int mih_host_loop = 0;                      // VC_MIH_HOST_LOOP=1: one host round trip per shell (the round-1 loop)
+};
+
 // ---- vc_scan.hip ------------------------------------------------------------------------------
 // Scan-kernel shape chosen per call: BLK threads, U column loads per thread per chunk.
 struct VcScanShape {
@@ -10,7 +25,7 @@ struct VcScanShape {
   int dbuf;     // register buffers per lane: 1 (rely on other waves), 2 (prefetch next chunk), 3 (two chunks ahead)
   uint64_t chunk_items() const { return 2ull * blk * unroll; }
 };
-VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes);
+VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes, const VcKnobs* knobs);
 
 float vc_probe_stream_ms(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t items, uint64_t* d_sink, uint32_t n_cu,
                          hipStream_t s);
@@ -25,9 +40,11 @@ hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t
 // distances <= tau[q]), then tau[q] = k-th smallest sampled distance.  d_shist [qt][hist_stride] must be zero.
 hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
-                                 uint32_t k, uint32_t bits, uint32_t* d_tau, uint32_t qs, bool refine, uint32_t n_cu, hipStream_t s);
+                                 uint32_t k, uint32_t bits, uint32_t* d_tau, uint32_t qs, bool refine, uint32_t n_cu,
+                                 uint32_t blocks_per_cu, hipStream_t s);
 // grid = min(chunks, CUs x resident blocks per CU, want_blocks if non-zero)
-hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, hipStream_t s);
+hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, const VcKnobs* knobs,
+                          hipStream_t s);
 // ring -> sorted top-k (per query); out padded with VC_PACK_INF
 // d_tau (nullable): final per-query distance thresholds of the scan -- farther entries are dropped before sorting
 hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_tau, uint32_t qs,
@@ -35,6 +52,14 @@ hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint
 // same, for the ring slots named in d_list (outputs indexed by slot)
 hipError_t vc_launch_select_ring_list(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_list,
                                       uint32_t n_list, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s);
+// Exact device-side recovery of the rows whose ring overflowed (count > cap), after vc_launch_select_ring on the same
+// buffers: no-op launch when nothing overflowed.  d_scratch: vc_recover_scratch_words() words, zero at first use
+// (the kernel restores its barrier words itself).  nq <= 64.
+size_t vc_recover_scratch_words();
+hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t id_base, uint32_t bits,
+                             const uint64_t* d_queries, uint32_t nq, uint32_t k, uint64_t* d_ring, uint32_t cap,
+                             const uint32_t* d_count, const uint32_t* d_hist, uint32_t hist_stride, uint32_t qs, uint32_t* d_scratch,
+                             uint64_t* d_out, uint32_t* d_out_count, uint32_t n_cu, hipStream_t s);
 // n_lists x [nq][k] sorted lists -> merged top-k
 hipError_t vc_launch_select_lists(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* d_out,
                                   uint32_t* d_out_count, hipStream_t s);

@@ -472,6 +472,7 @@ __global__ void __launch_bounds__(256) vc_seg_bounds_kernel(const uint32_t* coun
 struct VcMihIndex {
   uint32_t W = 0, m = 0, sbits = 0, id_base = 0, flags = 0, n_cu = 0, cap = 0;
   uint64_t n = 0;
+  VcKnobs knobs;   // environment knobs of the owning engine (read at vc_create)
   std::vector<VcTableView> h_tables;
   VcTableView* d_tables = nullptr;
   std::vector<void*> allocs;
@@ -519,8 +520,8 @@ void vc_mih_free(VcMihIndex* ix) {
 }
 
 int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t m,
-                 uint32_t sbits, uint32_t id_base, uint32_t flags, uint32_t n_cu, uint32_t cand_cap, hipStream_t s,
-                 std::string* err) {
+                 uint32_t sbits, uint32_t id_base, uint32_t flags, uint32_t n_cu, uint32_t cand_cap, const VcKnobs& knobs,
+                 hipStream_t s, std::string* err) {
   if (sbits != 8 && sbits != 16 && sbits != 32) {
     if (err) *err = "substring width must be 8, 16 or 32 bits (bits / n_tables)";
     return VC_ERR_INVALID;
@@ -529,6 +530,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
   if (rc) return rc;
   VcMihIndex* ix = new VcMihIndex();
   ix->W = W; ix->m = m; ix->sbits = sbits; ix->id_base = id_base; ix->flags = flags; ix->n_cu = n_cu; ix->cap = cand_cap; ix->n = n;
+  ix->knobs = knobs;
   ix->h_tables.resize(m);
   auto fail_free = [&](int code) { vc_mih_free(ix); return code; };
   auto dalloc = [&](void** p, size_t bytes, bool keep) -> hipError_t {
@@ -543,7 +545,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
   {
     size_t free_b = 0, total_b = 0;
     if (want_bcodes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * W * 8 > free_b / 3) want_bcodes = false;
-    if (const char* v = getenv("VC_MIH_BCODES")) want_bcodes = atoi(v) != 0;
+    if (knobs.mih_bcodes >= 0) want_bcodes = knobs.mih_bcodes != 0;   // dev knob VC_MIH_BCODES
   }
   const uint64_t nkeyspace = 1ull << sbits;
   const uint64_t bm_words = std::max<uint64_t>(nkeyspace / 32, 8);
@@ -796,7 +798,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
     hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, cur, (uint64_t)VC_PACK_INF);
     MIH_CHECK(hipGetLastError());
     uint32_t n_cur = qt;
-    const bool trace = getenv("VC_MIH_TRACE") != nullptr;   // per-shell wall times on stderr
+    const bool trace = ix->knobs.mih_trace;   // VC_MIH_TRACE: per-shell wall times on stderr
     for (uint32_t r = 0; r <= S && n_cur; ++r) {       // search_worker.cc:170: radius <= n_local_bytes_*8
       const auto t_shell = std::chrono::steady_clock::now();
       ProbeParams p{};
@@ -965,13 +967,13 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
         hipLaunchKernelGGL(vc_fill_u32_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, d_tau, qt, radius);
         R_CHECK(hipGetLastError());
         size_t lds;
-        const VcScanShape sh = vc_scan_pick_shape(W, qt, &lds);
+        const VcScanShape sh = vc_scan_pick_shape(W, qt, &lds, nullptr);
         VcScanParams p{};
         p.cols = d_cols; p.stride = stride; p.n = n; p.nchunks = (n + sh.chunk_items() - 1) / sh.chunk_items();
         p.id_base = id_base; p.qt = qt; p.k = 0xFFFFFFFFu;   // never re-derive tau: it is the fixed radius
         p.cap = cap; p.hist_stride = hs; p.queries = d_q + (size_t)q0 * W; p.tau = d_tau; p.count = d_count; p.qs = 1;
         p.hist = d_hist; p.buf = d_ring;
-        R_CHECK(vc_launch_scan(p, W, n_cu, 0, s));
+        R_CHECK(vc_launch_scan(p, W, n_cu, 0, nullptr, s));
       }
       R_CHECK(hipMemcpyAsync(h_count.data(), d_count, qt * 4, hipMemcpyDeviceToHost, s));
       R_CHECK(hipStreamSynchronize(s));

@@ -1,12 +1,12 @@
 // Multi-index-hashing side of the engine (vc_mih.hip): index build, bucket views, radius-incremental search.
 #pragma once
-#include "vc_common.hpp"
+#include "vc_internal.hpp"
 
 struct VcMihIndex;
 
 int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t m,
-                 uint32_t sbits, uint32_t id_base, uint32_t flags, uint32_t n_cu, uint32_t cand_cap, hipStream_t s,
-                 std::string* err);
+                 uint32_t sbits, uint32_t id_base, uint32_t flags, uint32_t n_cu, uint32_t cand_cap, const VcKnobs& knobs,
+                 hipStream_t s, std::string* err);
 void vc_mih_free(VcMihIndex* ix);
 // d_q [nq][W]; d_out [nq][k] ascending INF-padded; d_cnt [nq]; stats (host, may be null) filled after a sync.
 int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint64_t n, const uint64_t* d_q, uint32_t nq,

@@ -555,11 +555,11 @@ struct VcListsSrc {
 #define VC_SEL_THREADS 1024
 #define VC_RANK_SORT_MAX 1024u
 
-__device__ __forceinline__ void vc_bitonic_lds(uint64_t* a, uint32_t P) {
+__device__ __forceinline__ void vc_bitonic_lds(uint64_t* a, uint32_t P, uint32_t nthreads = VC_SEL_THREADS) {
   for (uint32_t size = 2; size <= P; size <<= 1) {
     for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
       __syncthreads();
-      for (uint32_t i = threadIdx.x; i < (P >> 1); i += VC_SEL_THREADS) {
+      for (uint32_t i = threadIdx.x; i < (P >> 1); i += nthreads) {
         const uint32_t lo = 2 * i - (i & (stride - 1));
         const uint32_t hi = lo + stride;
         const uint64_t x = a[lo], y = a[hi];
@@ -752,12 +752,304 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Ring-overflow recovery on the device (no host round trip, so the device-pointer API stays exact and asynchronous).
+//
+// A ring overflows when more than `cap` items lie at or below the k-th distance D: fewer than k items are nearer
+// than D (all of them are wanted) and thousands tie at exactly D, of which the canonical contract keeps the
+// need = k - #{d < D} SMALLEST ids (linear_search.cc:53 never replaces an equal-distance item, so the reference keeps
+// early = low ids too).  ids are positions (id = id_base + position, build_hash_tables.cc:55,61), so the wanted tie
+// with the largest id is found by a radix select over the POSITION of the ties:
+//   * D and need come from the scan's distance histogram, which is exact for every d <= D (the running threshold
+//     never drops below D, so every such item was counted whether its ring slot existed or not);
+//   * level 0 histograms position >> s0 of every tie over the whole database (2048 bins), level 1 / 2 refine inside
+//     the bin that holds the need-th tie (ranges of n/2048, n/2048^2 items) down to one position p*;
+//   * one more pass appends every item with (dist, id) <= (D, id_base + p*): exactly k of them, so the ring cannot
+//     overflow again, and one block per query sorts them into the output row.
+// Two full passes over the codes + two short ones, whatever the ring size, against the 2..200 host-driven rounds
+// of linear_recover() (vc_engine.hip), which stays as the fallback.
+//
+// One persistent launch after every select: without an overflowed query each block reads the ring cursors and
+// leaves (a ~2 us launch); otherwise the passes are separated by grid barriers, so every block must be resident
+// (2 blocks of 256 threads per CU, 64 KiB of LDS each) and every spin is bounded: if the grid cannot meet (another
+// kernel holds the CUs for seconds) the blocks give up, the row keeps its UINT32_MAX count and the sticky
+// `gave_up` counter reports it (vc_device_status).
+// ------------------------------------------------------------------------------------------
+#define VC_REC_RQ 8u            // overflowed queries recovered per round of passes (they share the two full sweeps)
+#define VC_REC_BINS 2048u
+#define VC_REC_MAXQ 64u         // = VC_GROUP_QUERIES: queries one select / recover launch serves
+#define VC_REC_SPIN_LIMIT (3u << 20)   // x s_sleep 32 (~0.9 us): ~3 s
+
+struct VcRecoverParams {
+  const uint64_t* cols;
+  uint64_t stride, n;
+  const uint64_t* queries;   // [nq][W]
+  const uint32_t* count;     // [nq] raw ring cursors of the scan (one per 128-byte line, `qs` words apart)
+  const uint32_t* hist;      // [nq][hist_stride] distance histogram of the scan
+  uint64_t* ring;            // [nq][cap]
+  uint32_t* idhist;          // [VC_REC_MAXQ][3][VC_REC_BINS] scratch, zeroed in here when needed
+  uint32_t* rcount;          // [VC_REC_MAXQ] ring cursors of the append pass, 32 words apart
+  uint32_t* bar;             // [0] arrivals, [32] give-up flag, [64] departures: all zero between launches
+  uint32_t* gave_up;         // sticky count of launches that gave up
+  uint64_t* out;             // [nq][k]
+  uint32_t* out_count;       // [nq]
+  uint32_t nq, k, cap, hist_stride, qs, bits, id_base;
+};
+
+// cut of a histogram plus the cumulative count below the cut bin (one wave; same result in every lane)
+__device__ __forceinline__ uint32_t vc_hist_cut_below(const uint32_t* h, uint32_t nbins, uint32_t k, uint32_t& below) {
+  const uint32_t lane = vc_lane();
+  const uint32_t bpl = (nbins + VC_WAVE - 1) / VC_WAVE;
+  uint32_t mine = 0;
+  for (uint32_t i = 0; i < bpl; ++i) {
+    const uint32_t bin = lane * bpl + i;
+    if (bin < nbins) mine += vc_ld_relaxed(h + bin);
+  }
+  uint32_t total;
+  uint32_t run = vc_wave_excl_scan(mine, total);
+  uint32_t cand = 0xFFFFFFFFu, before = 0;
+  for (uint32_t i = 0; i < bpl; ++i) {
+    const uint32_t bin = lane * bpl + i;
+    if (bin < nbins) {
+      const uint32_t c = vc_ld_relaxed(h + bin);
+      if (run + c >= k && cand == 0xFFFFFFFFu) {
+        cand = bin;
+        before = run;
+      }
+      run += c;
+    }
+  }
+  const uint32_t cut = vc_wave_min(cand);
+  const uint64_t owner = __ballot(cand == cut && cut != 0xFFFFFFFFu);
+  below = owner ? __shfl(before, __ffsll((long long)owner) - 1, VC_WAVE) : 0u;
+  return cut;
+}
+
+// grid barrier with a bounded spin; false = some block gave up (every block then leaves)
+__device__ __forceinline__ bool vc_rec_barrier(uint32_t* bar, uint32_t& epoch, uint32_t* s_ok) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup barrier
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back must have landed before the arrival shows (hipcc may drop its own wait)
+    ++epoch;
+    atomicAdd(&bar[0], 1u);
+    const uint32_t target = epoch * gridDim.x;
+    bool ok = true;
+    for (uint32_t spins = 0; vc_ld_relaxed(&bar[0]) < target; ++spins) {
+      __builtin_amdgcn_s_sleep(32);
+      if (spins > VC_REC_SPIN_LIMIT || vc_ld_relaxed(&bar[32])) {
+        ok = false;
+        break;
+      }
+    }
+    if (!ok) atomicExch(&bar[32], 1u);
+    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate completes asynchronously: hold the barrier until it has
+    *s_ok = ok ? 1u : 0u;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256, 2) vc_recover_kernel(const VcRecoverParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* lh = (uint32_t*)smem;   // [VC_REC_RQ][VC_REC_BINS] block-local position histograms; later the sort buffer
+  __shared__ uint32_t s_list[VC_REC_MAXQ];
+  __shared__ uint32_t s_nover, s_ok;
+  __shared__ uint64_t s_q[VC_REC_RQ][W];
+  __shared__ uint32_t s_D[VC_REC_RQ], s_need[VC_REC_RQ];
+  __shared__ uint64_t s_lo[VC_REC_RQ], s_lim[VC_REC_RQ];
+  const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
+
+  // ---- which queries overflowed?  (ring cursors of the finished scan: the same answer in every block)
+  if (threadIdx.x < VC_WAVE) {
+    const bool over = threadIdx.x < p.nq && p.count[(size_t)threadIdx.x * p.qs] > p.cap;
+    const uint64_t m = __ballot(over);
+    if (over) s_list[__popcll(m & ((1ull << lane) - 1ull))] = threadIdx.x;
+    if (lane == 0) s_nover = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  const uint32_t n_over = s_nover;
+  if (n_over == 0) return;
+
+  uint32_t epoch = 0;
+  bool alive = true;
+  // scratch of this launch: position histograms and append cursors of every overflowed query
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)n_over * 3 * VC_REC_BINS; i += (uint64_t)gridDim.x * blockDim.x)
+    p.idhist[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < n_over) p.rcount[threadIdx.x * 32] = 0;
+  alive = vc_rec_barrier(p.bar, epoch, &s_ok);
+
+  // position bits and the digit shifts of the (up to three) levels
+  uint32_t P = 1;
+  while (P < 32 && (1ull << P) < p.n) ++P;
+  const uint32_t nlev = P <= 11 ? 1u : (P <= 22 ? 2u : 3u);
+  const uint32_t shifts[3] = {P > 11 ? P - 11 : 0u, P > 22 ? P - 22 : 0u, 0u};
+
+  // one sweep over positions [lo, hi) for the queries [rb, re) of the round.  count: ties (d == D) are histogrammed
+  // by (position - base) >> shift into lh[r]; append: items with packed <= s_lim[r] go to the query's ring.
+  auto sweep = [&](uint64_t lo, uint64_t hi, uint32_t rb, uint32_t re, bool append, uint32_t shift, uint32_t slot0) {
+    if (hi > p.n) hi = p.n;
+    if (lo >= hi) return;
+    for (uint64_t c = lo / 2048 + blockIdx.x; c * 2048 < hi; c += gridDim.x) {
+      vc_u64x2 v[4][W];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          v[u][j] = __builtin_nontemporal_load(
+              reinterpret_cast<const vc_u64x2*>(p.cols + (uint64_t)j * p.stride + c * 2048 + (uint64_t)u * 512 + 2 * threadIdx.x));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t ia = c * 2048 + (uint64_t)u * 512 + 2 * threadIdx.x;
+        uint64_t a[W], b[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          a[j] = v[u][j].x;
+          b[j] = v[u][j].y;
+        }
+        const bool va = ia >= lo && ia < hi, vb = ia + 1 >= lo && ia + 1 < hi;
+        for (uint32_t r = rb; r < re; ++r) {
+          uint64_t qw[W];
+#pragma unroll
+          for (int j = 0; j < W; ++j) qw[j] = s_q[r][j];
+          const uint32_t da = vc_dist<W>(a, qw), db = vc_dist<W>(b, qw);
+          if (!append) {
+            const uint32_t D = s_D[r];
+            const uint64_t base = s_lo[r];
+            if (va && da == D) atomicAdd(&lh[r * VC_REC_BINS + (uint32_t)((ia - base) >> shift)], 1u);
+            if (vb && db == D) atomicAdd(&lh[r * VC_REC_BINS + (uint32_t)((ia + 1 - base) >> shift)], 1u);
+          } else {
+            const uint64_t lim = s_lim[r];
+            const uint64_t pa = vc_pack(da, p.id_base + (uint32_t)ia), pb = vc_pack(db, p.id_base + (uint32_t)ia + 1);
+            const bool oka = va && pa <= lim, okb = vb && pb <= lim;
+            const uint32_t cnt = (uint32_t)oka + (uint32_t)okb;
+            if (__ballot(cnt != 0) == 0) continue;
+            uint32_t total;
+            uint32_t pos = vc_wave_excl_scan(cnt, total);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&p.rcount[(slot0 + r) * 32], total);
+            pos += __builtin_amdgcn_readfirstlane(base);
+            uint64_t* ring = p.ring + (uint64_t)s_list[slot0 + r] * p.cap;
+            if (oka) {
+              if (pos < p.cap) ring[pos] = pa;
+              ++pos;
+            }
+            if (okb && pos < p.cap) ring[pos] = pb;
+          }
+        }
+      }
+    }
+  };
+  // flush lh[r] into the global histogram of (query slot, level), then clear it
+  auto flush = [&](uint32_t nr, uint32_t slot0, uint32_t level) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nr * VC_REC_BINS; i += blockDim.x) {
+      const uint32_t c = lh[i];
+      if (c) atomicAdd(&p.idhist[((uint64_t)(slot0 + i / VC_REC_BINS) * 3 + level) * VC_REC_BINS + i % VC_REC_BINS], c);
+      lh[i] = 0;
+    }
+    __syncthreads();
+  };
+  // after the barrier: every block locates the bin holding the need-th tie of each query of the round (one wave per query)
+  auto locate = [&](uint32_t nr, uint32_t slot0, uint32_t level, uint32_t shift) {
+    for (uint32_t r = wave; r < nr; r += blockDim.x / VC_WAVE) {
+      uint32_t before;
+      const uint32_t b = vc_hist_cut_below(p.idhist + ((uint64_t)(slot0 + r) * 3 + level) * VC_REC_BINS, VC_REC_BINS, s_need[r], before);
+      if (lane == 0) {
+        if (b == 0xFFFFFFFFu) {   // cannot happen (the ties were counted by the scan); poison the limit so the row stays flagged
+          s_need[r] = 0xFFFFFFFFu;
+        } else {
+          s_lo[r] += (uint64_t)b << shift;
+          s_need[r] -= before;
+        }
+      }
+    }
+    __syncthreads();
+  };
+
+  for (uint32_t r0 = 0; r0 < n_over && alive; r0 += VC_REC_RQ) {
+    const uint32_t nr = min(VC_REC_RQ, n_over - r0);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nr * W; i += blockDim.x) s_q[i / W][i % W] = p.queries[(uint64_t)s_list[r0 + i / W] * W + i % W];
+    for (uint32_t i = threadIdx.x; i < VC_REC_RQ * VC_REC_BINS; i += blockDim.x) lh[i] = 0;
+    for (uint32_t r = wave; r < nr; r += blockDim.x / VC_WAVE) {   // k-th distance D and the ties wanted at D
+      uint32_t below;
+      const uint32_t D = vc_hist_cut_below(p.hist + (uint64_t)s_list[r0 + r] * p.hist_stride, p.bits + 1, p.k, below);
+      if (lane == 0) {
+        s_D[r] = D;
+        s_need[r] = p.k - below;
+        s_lo[r] = 0;
+      }
+    }
+    __syncthreads();
+    // level 0: the whole database once for all queries of the round
+    sweep(0, p.n, 0, nr, false, shifts[0], r0);
+    flush(nr, r0, 0);
+    if (!(alive = vc_rec_barrier(p.bar, epoch, &s_ok))) break;
+    locate(nr, r0, 0, shifts[0]);
+    // deeper levels: only the bin that holds the need-th tie, per query
+    for (uint32_t l = 1; l < nlev && alive; ++l) {
+      for (uint32_t r = 0; r < nr; ++r) sweep(s_lo[r], s_lo[r] + (1ull << shifts[l - 1]), r, r + 1, false, shifts[l], r0);
+      flush(nr, r0, l);
+      if (!(alive = vc_rec_barrier(p.bar, epoch, &s_ok))) break;
+      locate(nr, r0, l, shifts[l]);
+    }
+    if (!alive) break;
+    // s_lo[r] is now the position of the last wanted tie: append everything at or below (D, id_base + position)
+    if (threadIdx.x < nr)
+      s_lim[threadIdx.x] = s_need[threadIdx.x] == 0xFFFFFFFFu ? 0ull : vc_pack(s_D[threadIdx.x], p.id_base + (uint32_t)s_lo[threadIdx.x]);
+    __syncthreads();
+    sweep(0, p.n, 0, nr, true, 0, r0);
+    if (!(alive = vc_rec_barrier(p.bar, epoch, &s_ok))) break;
+    // block r sorts query r's k entries into its output row
+    if (blockIdx.x < nr) {
+      const uint32_t r = blockIdx.x, q = s_list[r0 + r];
+      const uint32_t got = vc_ld_relaxed(&p.rcount[(r0 + r) * 32]);
+      if (got == p.k && p.k <= VC_SORT_CAP) {   // anything else would be a logic error: leave the row flagged
+        uint64_t* a = (uint64_t*)smem;
+        uint32_t PP = 2;
+        while (PP < got) PP <<= 1;
+        for (uint32_t i = threadIdx.x; i < PP; i += blockDim.x)
+          a[i] = i < got ? __hip_atomic_load(p.ring + (uint64_t)q * p.cap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : VC_PACK_INF;
+        vc_bitonic_lds(a, PP, blockDim.x);
+        for (uint32_t i = threadIdx.x; i < p.k; i += blockDim.x) p.out[(uint64_t)q * p.k + i] = a[i];
+        if (threadIdx.x == 0) p.out_count[q] = got;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < VC_REC_RQ * VC_REC_BINS; i += blockDim.x) lh[i] = 0;
+      }
+    }
+  }
+  // the last block to leave restores the barrier words (and records a give-up once)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&p.bar[64], 1u) == gridDim.x - 1) {
+      if (vc_ld_relaxed(&p.bar[32])) atomicAdd(p.gave_up, 1u);
+      atomicExch(&p.bar[0], 0u);
+      atomicExch(&p.bar[32], 0u);
+      atomicExch(&p.bar[64], 0u);
+    }
+  }
+}
+
 // persistent grid: every block must be resident (a block that waits for a slot would start when the others
 // have almost finished), so grid = CUs x blocks the kernel's registers/LDS admit per CU, capped by the request
 template <class K>
 uint32_t resident_grid(K kernel, int blk, size_t lds, uint32_t n_cu, uint32_t want) {
+  // the occupancy answer depends on (kernel, block, LDS) only: remember it per calling thread instead of asking
+  // the runtime on every launch (it is on the per-step host path)
+  struct Key { const void* k; int blk; size_t lds; int per_cu; };
+  static thread_local std::vector<Key> cache;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, blk, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  for (const Key& c : cache)
+    if (c.k == (const void*)kernel && c.blk == blk && c.lds == lds) per_cu = c.per_cu;
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, blk, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    cache.push_back(Key{(const void*)kernel, blk, lds, per_cu});
+  }
   const uint32_t cap = n_cu * (uint32_t)per_cu;
   return want ? std::min(want, cap) : cap;
 }
@@ -793,7 +1085,7 @@ hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t ld
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
-VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes) {
+VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes, const VcKnobs* knobs) {
   const size_t lds = (size_t)qt * (W * 8 + 4);
   if (lds_bytes) *lds_bytes = lds;
   VcScanShape sh;
@@ -802,13 +1094,11 @@ VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes) {
   // big LDS tiles leave room for one block per CU only: use 512 threads to keep 2 waves per SIMD.
   sh.blk = lds > 40 * 1024 ? 512 : 256;
   sh.dbuf = 2;
-  if (const char* e = getenv("VC_SCAN_SHAPE")) {  // dev knob: "U,BLK,DB"
-    int u = sh.unroll, b = sh.blk, d = sh.dbuf;
-    if (sscanf(e, "%d,%d,%d", &u, &b, &d) >= 1) {
-      if ((u == 1 || u == 2 || u == 4) && u * (int)W <= 8) sh.unroll = u;
-      if (b == 256 || b == 512) sh.blk = b;
-      sh.dbuf = d <= 0 ? 1 : (d >= 3 ? 3 : (d == 1 ? 2 : d));   // 0 -> 1 buffer, 1/2 -> 2, 3 -> 3
-    }
+  if (knobs && knobs->shape_set) {  // dev knob VC_SCAN_SHAPE "U,BLK,DB" (read at vc_create)
+    const int u = knobs->shape_u ? knobs->shape_u : sh.unroll, b = knobs->shape_blk ? knobs->shape_blk : sh.blk, d = knobs->shape_db;
+    if ((u == 1 || u == 2 || u == 4) && u * (int)W <= 8) sh.unroll = u;
+    if (b == 256 || b == 512) sh.blk = b;
+    sh.dbuf = d <= 0 ? 1 : (d >= 3 ? 3 : (d == 1 ? 2 : d));   // 0 -> 1 buffer, 1/2 -> 2, 3 -> 3
   }
   return sh;
 }
@@ -867,7 +1157,8 @@ hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t
 
 hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
-                                 uint32_t k, uint32_t bits, uint32_t* d_tau, uint32_t qs, bool refine, uint32_t n_cu, hipStream_t s) {
+                                 uint32_t k, uint32_t bits, uint32_t* d_tau, uint32_t qs, bool refine, uint32_t n_cu,
+                                 uint32_t blocks_per_cu, hipStream_t s) {
   if (qt == 0) return hipSuccess;
   if (s_items == 0) {   // nothing to sample: the cut of the (zero) histogram = "accept everything"
     hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u, qs);
@@ -875,8 +1166,7 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
   }
   const uint32_t gy = (qt + VC_SAMPLE_QSUB - 1) / VC_SAMPLE_QSUB;
   const uint64_t npairs = std::max<uint64_t>((s_items + 1) / 2, 1);
-  uint64_t per_cu = 8;
-  if (const char* g = getenv("VC_SAMPLE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(g));   // dev knob
+  const uint64_t per_cu = blocks_per_cu ? blocks_per_cu : 8;
   const uint32_t gx = (uint32_t)std::min<uint64_t>((npairs + 255) / 256, (uint64_t)n_cu * per_cu);
   const size_t lds = (size_t)VC_SAMPLE_QSUB * W * 8 + (size_t)VC_SAMPLE_QSUB * hist_stride * 4 + VC_SAMPLE_QSUB * 4;
   VcSampleParams p{cols, stride, s_items, d_queries, d_shist, d_tau, qt, hist_stride, refine ? 1u : 0u, qs};
@@ -899,10 +1189,11 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
   return hipGetLastError();
 }
 
-hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, hipStream_t s) {
+hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, const VcKnobs* knobs,
+                          hipStream_t s) {
   if (p.nchunks == 0 || p.qt == 0) return hipSuccess;
   size_t lds;
-  const VcScanShape sh = vc_scan_pick_shape(W, p.qt, &lds);
+  const VcScanShape sh = vc_scan_pick_shape(W, p.qt, &lds, knobs);
   switch (W) {
     case 1: return launch_scan_w<1>(p, sh, lds, n_cu, want_blocks, s);
     case 2: return launch_scan_w<2>(p, sh, lds, n_cu, want_blocks, s);
@@ -925,6 +1216,44 @@ hipError_t vc_launch_select_ring_list(const uint64_t* d_buf, uint32_t cap, const
   if (n_list == 0) return hipSuccess;
   VcRingSrc src{d_buf, d_count, cap, d_list, 0u, nullptr, 1u};
   hipLaunchKernelGGL((vc_select_kernel<VcRingSrc>), dim3(n_list), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
+  return hipGetLastError();
+}
+
+size_t vc_recover_scratch_words() {   // idhist | rcount lines | barrier lines (3 x 32 words) | gave_up
+  return (size_t)VC_REC_MAXQ * 3 * VC_REC_BINS + (size_t)VC_REC_MAXQ * 32 + 96 + 32;
+}
+
+hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t id_base, uint32_t bits,
+                             const uint64_t* d_queries, uint32_t nq, uint32_t k, uint64_t* d_ring, uint32_t cap,
+                             const uint32_t* d_count, const uint32_t* d_hist, uint32_t hist_stride, uint32_t qs, uint32_t* d_scratch,
+                             uint64_t* d_out, uint32_t* d_out_count, uint32_t n_cu, hipStream_t s) {
+  if (nq == 0 || n == 0) return hipSuccess;
+  if (nq > VC_REC_MAXQ) return hipErrorInvalidValue;
+  VcRecoverParams p{};
+  p.cols = cols; p.stride = stride; p.n = n; p.queries = d_queries; p.count = d_count; p.hist = d_hist; p.ring = d_ring;
+  p.idhist = d_scratch;
+  p.rcount = d_scratch + (size_t)VC_REC_MAXQ * 3 * VC_REC_BINS;
+  p.bar = p.rcount + (size_t)VC_REC_MAXQ * 32;
+  p.gave_up = p.bar + 96;
+  p.out = d_out; p.out_count = d_out_count;
+  p.nq = nq; p.k = k; p.cap = cap; p.hist_stride = hist_stride; p.qs = qs; p.bits = bits; p.id_base = id_base;
+  const size_t lds = (size_t)VC_REC_RQ * VC_REC_BINS * 4;
+#define VC_REC_CASE(W_)                                                                                              \
+  case W_: {                                                                                                         \
+    auto kern = vc_recover_kernel<W_>;                                                                               \
+    const uint32_t grid = std::min(2 * n_cu, resident_grid(kern, 256, lds, n_cu, 0));                                \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);                                                       \
+    break;                                                                                                           \
+  }
+  switch (W) {
+    VC_REC_CASE(1)
+    VC_REC_CASE(2)
+    VC_REC_CASE(4)
+    VC_REC_CASE(8)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef VC_REC_CASE
   return hipGetLastError();
 }
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "vc_create", "vc_destroy", "vc_last_error", "vc_strerror", "vc_abi_version", "vc_add_codes", "vc_add_synthetic",
     "vc_size", "vc_get_code", "vc_build_index", "vc_get_bucket", "vc_bitmap_test", "vc_bitmap_read", "vc_search_knn",
     "vc_search_knn_dev", "vc_search_radius", "vc_merge_topk_dev", "vc_get_timing", "vc_set_stream",
-    "vc_load_code_file", "vc_save_code_file", "vc_write_bitmap_file",
+    "vc_load_code_file", "vc_save_code_file", "vc_write_bitmap_file", "vc_device_status",
 ]
 
 
@@ -102,6 +102,7 @@ def load_library():
     L.vc_write_bitmap_file.argtypes = [vp, u32, C.c_char_p]
     L.vc_get_timing.argtypes = [vp, C.POINTER(VcTiming)]
     L.vc_set_stream.argtypes = [vp, vp]
+    L.vc_device_status.argtypes = [vp, C.POINTER(u32)]
     for name in EXPORTS:
         if getattr(L, name).restype is not C.c_char_p:
             getattr(L, name).restype = C.c_int
@@ -262,6 +263,12 @@ class Engine:
         t = VcTiming()
         self._check(self._L.vc_get_timing(self._h, C.byref(t)))
         return t
+
+    def device_status(self):
+        """calls since the last query whose device-side ring-overflow recovery gave up (0 in normal operation)"""
+        n = C.c_uint32()
+        self._check(self._L.vc_device_status(self._h, C.byref(n)))
+        return n.value
 
     def set_stream(self, stream):
         self._check(self._L.vc_set_stream(self._h, stream))

@@ -49,6 +49,10 @@ class GpuBackend:
     def timing(self):
         return self.engine.timing()
 
+    def unrecovered(self):
+        """calls whose device-side ring-overflow recovery gave up since the last query (vc_device_status); 0 normally"""
+        return self.engine.device_status()
+
     def close(self):
         self.engine.close()
 
@@ -195,6 +199,14 @@ class ShardedSearch:
         dist.all_gather_into_tensor(gath.view(self.world * nq, k), local, group=self.group)  # rank-major concat
         self.backend.merge(gath, self.world, nq, k, out, ocnt)
         return out, ocnt
+
+    def unrecovered(self):
+        """Diagnostic of the asynchronous path: number of local search calls since the last check in which a
+        candidate-ring overflow could NOT be recovered on the device (the affected rows are upper bounds only and the
+        batch should be re-run through Engine.search_knn).  The device recovery is exact and self-contained, so this
+        is 0 unless the GPU was held by foreign kernels for seconds.  Synchronises the local stream."""
+        f = getattr(self.backend, "unrecovered", None)
+        return f() if f else 0
 
     def close(self):
         self.backend.close()
