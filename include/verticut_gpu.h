@@ -182,6 +182,14 @@ int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t
 int vc_search_radius(vc_engine* e, const void* queries, uint32_t nq, uint32_t radius, uint32_t mode,
                      uint64_t* out, uint64_t out_cap, uint64_t* out_offsets);
 
+/* Device-pointer variant (queries and results stay in HBM): d_queries nq*bits/8 bytes, d_out out_cap packed values,
+ * d_offsets nq+1 entries, all device memory.  The work is enqueued on `stream`; the host synchronises that stream once,
+ * at the end, to learn the total (and repeats the call internally with a larger work ring if a query outgrew it).
+ * VC_ERR_CAPACITY if the results do not fit out_cap (d_offsets then holds the needed counts).
+ * replaces: the same reference loop as vc_search_radius (search_worker.cc:222-264). */
+int vc_search_radius_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t radius, uint32_t mode,
+                         uint64_t* d_out, uint64_t out_cap, uint64_t* d_offsets, void* stream);
+
 /* Sticky status of the asynchronous device path: *n_gave_up = calls since the previous vc_device_status() in which the
  * device-side ring-overflow recovery could not complete (its grid never met: the GPU was held by other kernels for
  * seconds); the affected queries kept d_counts[i] == UINT32_MAX.  0 in normal operation.  Synchronises the stream.

@@ -58,6 +58,26 @@ __device__ __forceinline__ uint32_t vc_wave_min(uint32_t v) {
   return v;
 }
 
+// in-place bitonic sort of a[0..P) (P a power of two) in LDS or global memory by one block of `nthreads` threads
+__device__ __forceinline__ void vc_bitonic_lds(uint64_t* a, uint32_t P, uint32_t nthreads) {
+  for (uint32_t size = 2; size <= P; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < (P >> 1); i += nthreads) {
+        const uint32_t lo = 2 * i - (i & (stride - 1));
+        const uint32_t hi = lo + stride;
+        const uint64_t x = a[lo], y = a[hi];
+        const bool up = (lo & size) == 0;
+        if ((x > y) == up) {
+          a[lo] = y;
+          a[hi] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ uint32_t vc_ld_relaxed(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -828,9 +828,26 @@ int vc_search_radius(vc_engine* e, const void* queries, uint32_t nq, uint32_t ra
   if ((rc = grow(e, &e->d_q, &e->q_bytes, qbytes))) return rc;
   VC_HIP(e, hipMemcpyAsync(e->d_q, queries, qbytes, hipMemcpyHostToDevice, e->stream));
   timing_begin(e);
-  rc = vc_radius_search(e->mih, mode == VC_MODE_MIH_EXACT, e->d_cols, e->stride, e->n, e->W, e->cfg.id_base, e->n_cu,
-                        e->d_q, nq, radius, out, out_cap, out_offsets, &e->radius_work, e->stream, &e->err);
+  rc = vc_radius_search(e->mih, mode == VC_MODE_MIH_EXACT, e->d_cols, e->stride, e->n, e->W, e->cfg.id_base, e->n_cu, &e->knobs,
+                        e->d_q, nq, radius, out, out_cap, out_offsets, false, &e->radius_work, e->stream, &e->err);
   timing_end(e);
+  return rc;
+}
+
+int vc_search_radius_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t radius, uint32_t mode, uint64_t* d_out,
+                         uint64_t out_cap, uint64_t* d_offsets, void* stream) {
+  if (!e || !d_queries || !d_offsets || (!d_out && out_cap) || nq == 0) return VC_ERR_INVALID;
+  if (mode != VC_MODE_LINEAR && mode != VC_MODE_MIH_EXACT) return fail(e, VC_ERR_INVALID, "radius search: mode must be LINEAR or MIH_EXACT");
+  if (mode == VC_MODE_MIH_EXACT && !e->mih) return fail(e, VC_ERR_STATE, "MIH search needs vc_build_index() first");
+  int rc = bind_device(e);
+  if (rc) return rc;
+  hipStream_t saved = e->stream;
+  e->stream = stream == VC_STREAM_OWN ? e->own_stream : (hipStream_t)stream;
+  timing_begin(e);
+  rc = vc_radius_search(e->mih, mode == VC_MODE_MIH_EXACT, e->d_cols, e->stride, e->n, e->W, e->cfg.id_base, e->n_cu, &e->knobs,
+                        (const uint64_t*)d_queries, nq, radius, d_out, out_cap, d_offsets, true, &e->radius_work, e->stream, &e->err);
+  timing_end(e);
+  e->stream = saved;
   return rc;
 }
 

@@ -31,7 +31,7 @@
 #define MIH_PPT 4                       // probes per thread
 #define MIH_EPT 4u                      // bucket entries per thread and round in the verify phase
 #define MIH_PCH (MIH_BLK * MIH_PPT)     // probes per block pass
-#define MIH_QTILE 256u                  // queries resident per search tile
+#define MIH_QTILE 1024u                 // queries resident per search tile (one block each in mih_query_kernel)
 #define MIH_APPROX_FACTOR 20u           // search_worker.h:14
 
 struct VcTableView {
@@ -433,9 +433,9 @@ __global__ void __launch_bounds__(256) mih_init_kernel(MihState st, uint32_t nq,
   list[i] = i;
 }
 
-__global__ void __launch_bounds__(256) mih_export_kernel(MihState st, uint32_t nq, uint32_t k, uint32_t cap,
+__global__ void __launch_bounds__(256) mih_export_kernel(MihState st, const uint32_t* __restrict__ list, uint32_t k, uint32_t cap,
                                                          uint64_t* __restrict__ out, uint32_t* __restrict__ cnt) {
-  const uint32_t q = blockIdx.x;
+  const uint32_t q = list ? list[blockIdx.x] : blockIdx.x;
   const uint32_t n = min(st.count[q], k);
   for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) out[(uint64_t)q * k + i] = i < n ? st.ring[(uint64_t)q * cap + i] : VC_PACK_INF;
   if (threadIdx.x == 0) cnt[q] = n;
@@ -446,22 +446,586 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
   if (i < n) p[i] = v;
 }
 
-// sorted ring segments -> one contiguous result array (offs = exclusive prefix of the segment lengths)
-__global__ void __launch_bounds__(256) vc_compact_segments_kernel(const uint64_t* __restrict__ sorted, uint32_t cap,
-                                                                  const uint64_t* __restrict__ offs, uint32_t nq,
-                                                                  uint64_t* __restrict__ out) {
-  const uint32_t q = blockIdx.x;
-  const uint64_t lo = offs[q] - offs[0], n = offs[q + 1] - offs[q];
-  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) out[lo + i] = sorted[(uint64_t)q * cap + i];
+// =============================================================================================================
+// mih_query_kernel -- ONE 256-thread block runs a query's whole radius loop (search_worker.cc:159-218 / 93-157,
+// shells 0..r_last) or a whole fixed-radius neighbour search (search_R_neighbors shells 0..R/m, :222-227) in ONE
+// launch: probe -> bucket lookup -> verify -> top-k merge -> stop rule, shell after shell, with no host round trip
+// and no kernel boundary between shells.  Queries are independent, so the grid is simply one block per query; what
+// the round-1 loop paid per shell (memset + probe + select + commit + an 8-byte read-back and ~20 us of host
+// turnaround, with one 256-thread block per (query, table) even for the 1-key shell) is gone.
+//
+// 32-bit substrings -- the reference's native shape -- are probed by GRANULE, not by key: the keys of a shell are
+// qkey ^ mask with popcount(mask) = r; split mask = (hi: 25 bits, lo: 7 bits).  All keys that share `hi` lie in ONE
+// aligned 128-bit granule of the occupancy bitmap (bit v of word v/32, bitmap.cc:22-26), so a lane loads that
+// granule once (one 16-byte load) and ANDs it with a per-query mask E_j = {x : popcount(x ^ qlo) = j}, j = r - |hi|
+// (radius search: the ball B_j = E_0 | .. | E_j), precomputed in LDS.  Shells 0..4 of a 32-bit substring are 41 449
+// keys but only 15 276 granules; a set bit of (granule & mask) is a non-empty bucket of the shell.
+// <= 16-bit substrings have direct offsets (two 4-byte loads per key), enumerated by combination unranking + Gosper.
+//
+// Per block: hits (non-empty buckets) are compacted into an LDS list; when it holds >= MQ_HFLUSH entries (and at the
+// end of a shell) it is DRAINED: rank -> offsets for the 32-bit tables, block prefix sum of the bucket lengths,
+// balanced expansion of the entries over the threads (binary search in the LDS prefix array), gather of id + code,
+// full distance + every substring distance, OWNER RULE (vc_mih.hip mih_probe_kernel), survivors below the current
+// k-th best appended behind the top-k in LDS.  The top-k array and the fresh candidates share one LDS buffer that is
+// bitonic-sorted when a shell ends (or when it fills), which also yields the new threshold and the stop rule's k-th
+// distance.  A query that is not finished after shell r_last (the shells beyond cost > 10^5 probes) writes its state
+// to the slot arrays and joins the `heavy` list, which the multi-block kernels above continue from shell r_last + 1.
+// =============================================================================================================
+#define MQ_BLK 256u
+#define MQ_G 4u                         // granules / keys per thread per pass
+#define MQ_PASS (MQ_BLK * MQ_G)
+#define MQ_HMAX 1024u                   // LDS hit list (non-empty buckets awaiting a drain)
+#define MQ_HFLUSH 512u
+#define MQ_ROUND (MQ_BLK * MIH_EPT)     // bucket entries verified per round
+#define MQ_BW 17u                       // row width of the LDS binomial table: C(c, i), c <= 32, i <= 16
+#define MQ_MODE_EXACT 0u
+#define MQ_MODE_APPROX 1u
+#define MQ_MODE_RADIUS 2u
+
+struct QueryKernelParams {
+  const uint64_t* cols;
+  uint64_t stride, n;
+  const VcTableView* tables;
+  const uint64_t* queries;     // [nq][W]
+  MihState st;
+  uint32_t m, sbits, id_base, flags, cap, k;
+  uint32_t mode;               // MQ_MODE_*
+  uint32_t radius;             // MQ_MODE_RADIUS: full-distance radius
+  uint32_t stop_mult;
+  uint32_t r_last;             // last shell run in here (radius mode: the substring radius)
+  uint32_t buf_entries;        // LDS top-k + candidate buffer (power of two, >= k + MQ_ROUND)
+  uint32_t* heavy_list;
+  uint32_t* heavy_ctr;
+  uint64_t* out;               // k-NN: [nq][k] rows
+  uint32_t* out_cnt;
+};
+
+__device__ __forceinline__ uint32_t mq_unrank(const uint32_t* sb, uint32_t j, uint32_t r, uint32_t s) {
+  uint32_t mask = 0, c = s;
+  for (uint32_t i = r; i >= 1; --i) {
+    do { --c; } while (sb[c * MQ_BW + i] > j);   // largest c with C(c,i) <= j
+    j -= sb[c * MQ_BW + i];
+    mask |= 1u << c;
+  }
+  return mask;
 }
 
-__global__ void __launch_bounds__(256) vc_seg_bounds_kernel(const uint32_t* count, uint32_t nq, uint32_t cap, uint32_t* beg,
-                                                            uint32_t* end) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq) {
-    beg[i] = i * cap;
-    end[i] = i * cap + min(count[i], cap);
+template <int W>
+__global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* s_buf = (uint64_t*)smem;                         // [buf_entries] top-k (sorted) | fresh candidates
+  uint32_t* s_key = (uint32_t*)(s_buf + p.buf_entries);      // [MQ_HMAX] bucket key, then bucket offset
+  uint32_t* s_pref = s_key + MQ_HMAX;                        // [MQ_HMAX + 1] bucket length, then exclusive prefix
+  uint32_t* s_meta = s_pref + MQ_HMAX + 1;                   // [MQ_HMAX] table | substring distance << 8
+  uint32_t* s_binom = s_meta + MQ_HMAX;                      // [33][MQ_BW]
+  uint32_t* s_mask = s_binom + 33 * MQ_BW;                   // [m][8][4] (32-bit substrings only)
+  __shared__ VcTableView s_tv[64];
+  __shared__ uint32_t s_nh, s_ncand, s_seen, s_hits0, s_wsum[MQ_BLK / VC_WAVE];
+  __shared__ uint32_t s_segstart[28], s_segh[27], s_segmask[27], s_nseg;
+  __shared__ uint64_t s_thresh;
+
+  const uint32_t slot = blockIdx.x;
+  const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
+  const uint32_t s = p.sbits, m = p.m;
+  const uint32_t smask = s == 32 ? 0xFFFFFFFFu : ((1u << s) - 1u);
+  const bool knn = p.mode != MQ_MODE_RADIUS;
+
+  uint64_t qw[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) qw[j] = p.queries[(uint64_t)slot * W + j];
+  auto qkey = [&](uint32_t t) {
+    const uint32_t bp = t * s;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if ((uint32_t)j == (bp >> 6)) v = (uint32_t)(qw[j] >> (bp & 63)) & smask;
+    return v;
+  };
+
+  for (uint32_t i = tid; i < 33 * MQ_BW; i += MQ_BLK) s_binom[i] = c_binom[i / MQ_BW][i % MQ_BW];
+  for (uint32_t i = tid; i < m * (sizeof(VcTableView) / 4); i += MQ_BLK) ((uint32_t*)s_tv)[i] = ((const uint32_t*)p.tables)[i];
+  if (s == 32)
+    for (uint32_t i = tid; i < m * 32; i += MQ_BLK) s_mask[i] = 0;
+  if (tid == 0) {
+    s_nh = 0;
+    s_ncand = 0;
+    s_seen = 0;
+    s_hits0 = 0;
+    s_thresh = knn ? VC_PACK_INF : vc_pack(p.radius + 1, 0);
   }
+  __syncthreads();
+  if (s == 32) {   // E_j[t] = { x < 128 : popcount(x ^ qlo_t) = j }; radius search: balls B_j = E_0 | ... | E_j
+    for (uint32_t i = tid; i < m * 128; i += MQ_BLK) {
+      const uint32_t t = i >> 7, x = i & 127u;
+      const uint32_t j = __popc(x ^ (qkey(t) & 127u));
+      atomicOr(&s_mask[(t * 8 + j) * 4 + (x >> 5)], 1u << (x & 31));
+    }
+    __syncthreads();
+    if (!knn) {
+      for (uint32_t i = tid; i < m * 4; i += MQ_BLK) {
+        const uint32_t t = i >> 2, w = i & 3u;
+        uint32_t acc = 0;
+        for (uint32_t j = 0; j < 8; ++j) {
+          acc |= s_mask[(t * 8 + j) * 4 + w];
+          s_mask[(t * 8 + j) * 4 + w] = acc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  uint32_t kk = 0;                 // committed top-k entries in s_buf[0..kk), ascending   (block-uniform)
+  bool spilled = false;            // radius mode: results went to the global ring unsorted (block-uniform)
+  uint32_t ring_fill = 0;          // radius mode: entries already in the global ring       (block-uniform)
+  unsigned long long sub = 0, loc = 0;   // get_stat counters of table 0 (block-uniform)
+  uint64_t* const ring = p.st.ring + (uint64_t)slot * p.cap;
+
+  // ---- sort s_buf[0 .. kk + ncand) and keep the k smallest: new top-k, new threshold
+  auto merge = [&]() {
+    __syncthreads();
+    const uint32_t total = kk + min(s_ncand, p.buf_entries - kk);
+    uint32_t P = 2;
+    while (P < total) P <<= 1;
+    for (uint32_t i = total + tid; i < P; i += MQ_BLK) s_buf[i] = VC_PACK_INF;
+    vc_bitonic_lds(s_buf, P, MQ_BLK);
+    kk = knn ? min(p.k, total) : total;
+    if (tid == 0) {
+      s_ncand = 0;
+      if (knn) s_thresh = kk == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
+    }
+    __syncthreads();
+  };
+  // ---- radius mode: move the LDS results to the global ring (unsorted; the count keeps running past cap)
+  auto flush_ring = [&]() {
+    __syncthreads();
+    const uint32_t nc = s_ncand;
+    for (uint32_t i = tid; i < nc; i += MQ_BLK)
+      if (ring_fill + i < p.cap) ring[ring_fill + i] = s_buf[i];
+    ring_fill += nc;
+    spilled = true;
+    __syncthreads();
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+  };
+
+  // ---- drain the hit list: (rank -> offsets), prefix sum, balanced verify
+  auto drain = [&]() {
+    __syncthreads();
+    const uint32_t H = min(s_nh, MQ_HMAX);
+    if (s == 32) {
+      for (uint32_t i = tid; i < H; i += MQ_BLK) {
+        const uint32_t key = s_key[i];
+        const VcTableView& tv = s_tv[s_meta[i] & 0xFFu];
+        const uint32_t rk = vc_rank32(tv.bitmap, tv.blockrank, key);
+        const uint32_t a = tv.offsets[rk], b = tv.offsets[rk + 1];
+        s_key[i] = a;
+        s_pref[i] = b - a;
+      }
+      __syncthreads();
+    }
+    uint32_t lsum = 0, lv[MQ_HMAX / MQ_BLK];
+#pragma unroll
+    for (uint32_t i = 0; i < MQ_HMAX / MQ_BLK; ++i) {
+      const uint32_t idx = tid * (MQ_HMAX / MQ_BLK) + i;
+      lv[i] = idx < H ? s_pref[idx] : 0;
+      lsum += lv[i];
+    }
+    uint32_t wtot;
+    uint32_t excl = vc_wave_excl_scan(lsum, wtot);
+    if (lane == 0) s_wsum[wave] = wtot;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < MQ_BLK / VC_WAVE; ++w) {
+      if (w < wave) wbase += s_wsum[w];
+      total += s_wsum[w];
+    }
+    excl += wbase;
+#pragma unroll
+    for (uint32_t i = 0; i < MQ_HMAX / MQ_BLK; ++i) {
+      const uint32_t idx = tid * (MQ_HMAX / MQ_BLK) + i;
+      if (idx < H) s_pref[idx] = excl;
+      excl += lv[i];
+    }
+    if (tid == 0) s_pref[H] = total;
+    __syncthreads();
+
+    uint32_t seen_acc = 0;
+    for (uint32_t e0 = 0; e0 < total; e0 += MQ_ROUND) {
+      // room for one round of survivors behind what the buffer already holds (the barrier makes the fill uniform)
+      __syncthreads();
+      if (kk + s_ncand + MQ_ROUND > p.buf_entries) {
+        if (knn) merge(); else flush_ring();
+      }
+      const uint64_t thresh = s_thresh;
+      uint32_t local[MIH_EPT], meta[MIH_EPT];
+      uint64_t x[MIH_EPT][W];
+      bool live[MIH_EPT];
+#pragma unroll
+      for (uint32_t g = 0; g < MIH_EPT; ++g) {
+        const uint32_t e = e0 + g * MQ_BLK + tid;
+        live[g] = e < total;
+        const uint32_t ec = live[g] ? e : 0;
+        uint32_t lo = 0, hi = H;               // largest b with s_pref[b] <= e
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_pref[mid] <= ec) lo = mid; else hi = mid;
+        }
+        meta[g] = s_meta[lo];
+        const VcTableView& tv = s_tv[meta[g] & 0xFFu];
+        const uint32_t pos = s_key[lo] + (ec - s_pref[lo]);
+        local[g] = tv.ids[pos];
+        if (tv.bcodes) {
+#pragma unroll
+          for (int j = 0; j < W; ++j) x[g][j] = tv.bcodes[(uint64_t)j * p.n + pos];
+        } else {
+#pragma unroll
+          for (int j = 0; j < W; ++j) x[g][j] = p.cols[(uint64_t)j * p.stride + local[g]];
+        }
+      }
+#pragma unroll
+      for (uint32_t g = 0; g < MIH_EPT; ++g) {
+        bool emit = live[g];
+        uint64_t packed = 0;
+        if (live[g]) {
+          const uint32_t t = meta[g] & 0xFFu, dt = meta[g] >> 8;
+          uint32_t dist = 0;
+          for (uint32_t tt = 0; tt < m; ++tt) {
+            const uint32_t bp = tt * s;
+            uint32_t field = 0;
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+              if ((uint32_t)j == (bp >> 6)) field = (uint32_t)((x[g][j] ^ qw[j]) >> (bp & 63)) & smask;
+            const uint32_t d = __popc(field);
+            dist += d;
+            // owner rule (see mih_probe_kernel): reported by the first table holding the minimum substring distance
+            bool reach = true;
+            if ((p.flags & VC_FLAG_REF_SIGNEXT_KEYS) && s < 32) reach = ((field >> (s - 1)) & 1u) == 0;
+            if (tt != t && reach && (d < dt || (d == dt && tt < t))) emit = false;
+          }
+          packed = vc_pack(dist, p.id_base + local[g]);
+        }
+        const uint64_t emask = __ballot(emit);
+        if (emask == 0) continue;
+        seen_acc += (uint32_t)__popcll(emask);
+        const bool keep = emit && packed < thresh;
+        const uint64_t kmask = __ballot(keep);
+        if (kmask == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_ncand, (uint32_t)__popcll(kmask));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (keep) s_buf[kk + base + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull))] = packed;
+      }
+    }
+    if (lane == 0 && seen_acc) atomicAdd(&s_seen, seen_acc);
+    __syncthreads();
+    if (tid == 0) s_nh = 0;
+    __syncthreads();
+  };
+
+  // ---- one table of one shell, 32-bit substrings: granule scan over the segments in s_seg*
+  auto scan32 = [&](uint32_t t) {
+    const VcTableView& tv = s_tv[t];
+    const uint32_t qk = qkey(t), qhi = qk >> 7, qlo = qk & 127u;
+    const uint32_t total = s_segstart[s_nseg];
+    for (uint32_t base = 0; base < total; base += MQ_PASS) {
+      const uint32_t idx0 = base + tid * MQ_G;
+      uint32_t seg = 0, hi = 0;
+      if (idx0 < total) {
+        while (idx0 >= s_segstart[seg + 1]) ++seg;
+        hi = mq_unrank(s_binom, idx0 - s_segstart[seg], s_segh[seg], 25);
+      }
+      uint4 v[MQ_G];
+      uint32_t gr[MQ_G], hh[MQ_G], mi[MQ_G];
+#pragma unroll
+      for (uint32_t g = 0; g < MQ_G; ++g) {
+        const uint32_t idx = idx0 + g;
+        gr[g] = 0; hh[g] = 0; mi[g] = 0;
+        v[g] = make_uint4(0, 0, 0, 0);
+        if (idx < total) {
+          if (g) {
+            if (idx == s_segstart[seg + 1]) {
+              ++seg;
+              hi = (1u << s_segh[seg]) - 1u;
+            } else {
+              hi = vc_next_comb(hi);
+            }
+          }
+          gr[g] = qhi ^ hi;
+          hh[g] = s_segh[seg];
+          mi[g] = s_segmask[seg];
+          v[g] = *reinterpret_cast<const uint4*>(tv.bitmap + ((uint64_t)gr[g] << 2));
+        }
+      }
+      uint32_t w[MQ_G][4];
+      uint32_t cnt = 0;
+#pragma unroll
+      for (uint32_t g = 0; g < MQ_G; ++g) {
+        const uint32_t* mk = s_mask + (t * 8 + mi[g]) * 4;
+        w[g][0] = v[g].x & mk[0];
+        w[g][1] = v[g].y & mk[1];
+        w[g][2] = v[g].z & mk[2];
+        w[g][3] = v[g].w & mk[3];
+        cnt += __popc(w[g][0]) + __popc(w[g][1]) + __popc(w[g][2]) + __popc(w[g][3]);
+      }
+      if (t == 0 && (p.flags & VC_FLAG_USE_BITMAP)) {   // n_sub_reads_ = leaves whose bit is set (search_worker.cc:238-245)
+        uint32_t wt;
+        (void)vc_wave_excl_scan(cnt, wt);
+        if (lane == 0 && wt) atomicAdd(&s_hits0, wt);
+      }
+      for (;;) {   // append this pass's hits; what does not fit waits for a drain
+        if (!__syncthreads_or(cnt != 0)) break;
+        uint32_t wtot;
+        const uint32_t off = vc_wave_excl_scan(cnt, wtot);
+        uint32_t wb = 0;
+        if (lane == 0 && wtot) wb = atomicAdd(&s_nh, wtot);
+        uint32_t pos = __builtin_amdgcn_readfirstlane(wb) + off;
+#pragma unroll
+        for (uint32_t g = 0; g < MQ_G; ++g)
+#pragma unroll
+          for (uint32_t i = 0; i < 4; ++i)
+            while (w[g][i] && pos < MQ_HMAX) {
+              const uint32_t b = (uint32_t)__ffs((int)w[g][i]) - 1u;
+              w[g][i] &= w[g][i] - 1u;
+              const uint32_t x = i * 32 + b;
+              s_key[pos] = (gr[g] << 7) | x;
+              s_meta[pos] = t | ((hh[g] + __popc(x ^ qlo)) << 8);
+              ++pos;
+              --cnt;
+            }
+        __syncthreads();
+        const uint32_t nh = s_nh;
+        if (nh >= MQ_HFLUSH) drain();
+        if (nh <= MQ_HMAX) break;               // everything fitted
+      }
+    }
+  };
+
+  // ---- one table of one shell, <= 16-bit substrings: direct offsets, keys by combination unranking + Gosper
+  auto scan_direct = [&](uint32_t t, uint32_t r) {
+    const VcTableView& tv = s_tv[t];
+    const uint32_t qk = qkey(t);
+    const uint32_t nkeys = s_binom[s * MQ_BW + r];
+    for (uint32_t base = 0; base < nkeys; base += MQ_PASS) {
+      const uint32_t j0 = base + tid * MQ_G;
+      uint32_t mask = j0 < nkeys ? mq_unrank(s_binom, j0, r, s) : 0u;
+      uint32_t offv[MQ_G], lenv[MQ_G];
+      uint32_t cnt = 0;
+#pragma unroll
+      for (uint32_t g = 0; g < MQ_G; ++g) {
+        offv[g] = 0;
+        lenv[g] = 0;
+        if (j0 + g < nkeys) {
+          if (g) mask = vc_next_comb(mask);
+          // binaryToInt's sign-extended keys (Pilaf/image_tools.h:13): a probe that flips the top bit matches nothing
+          const bool dead = (p.flags & VC_FLAG_REF_SIGNEXT_KEYS) && ((mask >> (s - 1)) & 1u);
+          if (!dead) {
+            const uint32_t key = qk ^ mask;
+            const uint32_t a = tv.offsets[key], b = tv.offsets[key + 1];
+            offv[g] = a;
+            lenv[g] = b - a;
+          }
+          cnt += lenv[g] != 0;
+        }
+      }
+      if (t == 0 && (p.flags & VC_FLAG_USE_BITMAP)) {
+        uint32_t wt;
+        (void)vc_wave_excl_scan(cnt, wt);
+        if (lane == 0 && wt) atomicAdd(&s_hits0, wt);
+      }
+      for (;;) {
+        if (!__syncthreads_or(cnt != 0)) break;
+        uint32_t wtot;
+        const uint32_t off = vc_wave_excl_scan(cnt, wtot);
+        uint32_t wb = 0;
+        if (lane == 0 && wtot) wb = atomicAdd(&s_nh, wtot);
+        uint32_t pos = __builtin_amdgcn_readfirstlane(wb) + off;
+#pragma unroll
+        for (uint32_t g = 0; g < MQ_G; ++g)
+          if (lenv[g] && pos < MQ_HMAX) {
+            s_key[pos] = offv[g];
+            s_pref[pos] = lenv[g];
+            s_meta[pos] = t | (r << 8);
+            lenv[g] = 0;
+            ++pos;
+            --cnt;
+          }
+        __syncthreads();
+        const uint32_t nh = s_nh;
+        if (nh >= MQ_HFLUSH) drain();
+        if (nh <= MQ_HMAX) break;
+      }
+    }
+  };
+
+  // ---- segments of one pass over a 32-bit table: exact shell r (masks E_{r-h}) or the whole ball (masks B_{R-h})
+  auto plan32 = [&](uint32_t r, bool ball) {
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t ns = 0, start = 0;
+      for (uint32_t h = 0; h <= min(r, 25u); ++h) {
+        const uint32_t j = r - h;
+        if (!ball && j > 7) continue;            // a 7-bit low part holds at most 7 flips
+        s_segstart[ns] = start;
+        s_segh[ns] = h;
+        s_segmask[ns] = min(j, 7u);
+        start += s_binom[25 * MQ_BW + h];
+        ++ns;
+      }
+      s_segstart[ns] = start;
+      s_nseg = ns;
+    }
+    __syncthreads();
+  };
+
+  const uint32_t S = s;            // loop bound radius <= n_local_bytes_ * 8 (search_worker.cc:170)
+  if (!knn) {
+    // fixed-radius neighbour search: shells 0 .. r_last of every table, every item within the full distance kept
+    if (s == 32) {
+      plan32(p.r_last, true);
+      for (uint32_t t = 0; t < m; ++t) scan32(t);
+    } else {
+      for (uint32_t r = 0; r <= p.r_last; ++r)
+        for (uint32_t t = 0; t < m; ++t) scan_direct(t, r);
+    }
+    if (s_nh) drain();
+    __syncthreads();
+    if (!spilled) {
+      merge();                                       // sorts the LDS results (kk = their number)
+      for (uint32_t i = tid; i < kk; i += MQ_BLK)
+        if (i < p.cap) ring[i] = s_buf[i];
+      if (tid == 0) {
+        p.st.count[slot] = kk;
+        p.st.topn[slot] = kk <= p.cap ? 1u : 0u;     // 1 = the ring segment is already sorted
+      }
+    } else {
+      flush_ring();
+      if (tid == 0) {
+        p.st.count[slot] = ring_fill;
+        p.st.topn[slot] = 0;
+      }
+    }
+    return;
+  }
+
+  for (uint32_t r = 0; r <= p.r_last; ++r) {
+    if (s == 32) {
+      plan32(r, false);
+      for (uint32_t t = 0; t < m; ++t) scan32(t);
+    } else {
+      for (uint32_t t = 0; t < m; ++t) scan_direct(t, r);
+    }
+    if (s_nh) drain();
+    __syncthreads();
+    if (s_ncand) merge();
+    // get_stat counters of table 0 (rank 0's, search_worker.cc:24-30): every leaf is a bitmap test when the bitmap
+    // is attached (:239) and a get only where the bit is set (:245); without it every leaf is a get
+    const unsigned long long leaves = c_binom[s][r];
+    if (p.flags & VC_FLAG_USE_BITMAP) {
+      loc += leaves;
+      sub += s_hits0;
+    } else {
+      sub += leaves;
+    }
+    __syncthreads();
+    if (tid == 0) s_hits0 = 0;
+    const uint64_t kth = kk == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
+    bool stop;
+    if (p.mode == MQ_MODE_APPROX)   // search_worker.cc:136-137: the heap of k*20 distinct candidates is full
+      stop = s_seen >= p.k * MIH_APPROX_FACTOR;
+    else                            // search_worker.cc:201-205: size == k && top.dist <= radius * 4 (radius already incremented)
+      stop = kk == p.k && (uint32_t)(kth >> 32) <= (r + 1) * p.stop_mult;
+    if (stop || r == S) {
+      for (uint32_t i = tid; i < p.k; i += MQ_BLK) p.out[(uint64_t)slot * p.k + i] = i < kk ? s_buf[i] : VC_PACK_INF;
+      if (tid == 0) {
+        p.out_cnt[slot] = kk;
+        p.st.radius[slot] = r;     // find() returns radius - 1 = last shell searched
+        p.st.seen[slot] = s_seen;
+        p.st.sub[slot] = sub;
+        p.st.loc[slot] = loc;
+      }
+      return;
+    }
+    __syncthreads();
+  }
+  // not finished: hand the query to the multi-block shells (state exactly as mih_commit_kernel leaves it)
+  for (uint32_t i = tid; i < kk; i += MQ_BLK) ring[i] = s_buf[i];
+  if (tid == 0) {
+    p.st.count[slot] = kk;
+    p.st.prev[slot] = kk;
+    p.st.thresh[slot] = kk == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
+    p.st.seen[slot] = s_seen;
+    p.st.sub[slot] = sub;
+    p.st.loc[slot] = loc;
+    p.st.radius[slot] = 0;
+    p.st.topn[slot] = kk;
+    p.heavy_list[atomicAdd(p.heavy_ctr, 1u)] = slot;
+  }
+}
+
+
+// per-query result segments of the radius search: ring[q][0 .. min(count, cap)) sorted ascending in place.
+// One 1024-thread block per query; segments the query kernel already sorted (flag) or empty ones are skipped.
+//   n <= 8192 : bitonic network in LDS;   larger: the same network on the segment itself (global memory), padded
+// to a power of two with VC_PACK_INF behind the entries (cap is a power of two).
+__global__ void __launch_bounds__(1024) vc_sort_segments_kernel(uint64_t* __restrict__ ring, uint32_t cap,
+                                                                const uint32_t* __restrict__ count,
+                                                                const uint32_t* __restrict__ sorted_flag) {
+  __shared__ uint64_t a[VC_SORT_CAP];
+  const uint32_t q = blockIdx.x;
+  const uint32_t n = count[q];
+  if (n < 2 || n > cap || (sorted_flag && sorted_flag[q])) return;
+  uint64_t* seg = ring + (uint64_t)q * cap;
+  uint32_t P = 2;
+  while (P < n) P <<= 1;
+  if (P <= VC_SORT_CAP) {
+    for (uint32_t i = threadIdx.x; i < P; i += 1024) a[i] = i < n ? seg[i] : VC_PACK_INF;
+    vc_bitonic_lds(a, P, 1024);
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) seg[i] = a[i];
+  } else {
+    for (uint32_t i = n + threadIdx.x; i < P; i += 1024) seg[i] = VC_PACK_INF;
+    vc_bitonic_lds(seg, P, 1024);
+  }
+}
+
+// exclusive prefix of one tile's segment lengths behind the running total of the call:
+// offsets[i] = tot[0] + sum_{j<i} count[j];  tot[0] += sum;  tot[1] = max(tot[1], max count)  (overflow detection)
+__global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t* __restrict__ count, uint32_t nq,
+                                                                 uint64_t* __restrict__ offsets, unsigned long long* tot) {
+  __shared__ uint64_t s_w[1024 / VC_WAVE];
+  __shared__ uint32_t s_max;
+  const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
+  const uint32_t c = threadIdx.x < nq ? count[threadIdx.x] : 0u;
+  uint32_t wtot;
+  const uint32_t ex = vc_wave_excl_scan(c, wtot);   // a wave's 64 counts stay far below 2^32 (cap <= 2^26)
+  if (lane == 0) s_w[wave] = wtot;
+  atomicMax(&s_max, c);
+  __syncthreads();
+  uint64_t base = tot[0], total = 0;
+  for (uint32_t w = 0; w < 1024 / VC_WAVE; ++w) {
+    if (w < wave) base += s_w[w];
+    total += s_w[w];
+  }
+  if (threadIdx.x < nq) offsets[threadIdx.x] = base + ex;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    offsets[nq] = tot[0] + total;
+    tot[0] += total;
+    if (s_max > tot[1]) tot[1] = s_max;
+  }
+}
+
+// sorted ring segments -> one contiguous result array (positions beyond out_cap are dropped; the caller learns the
+// needed size from the offsets)
+__global__ void __launch_bounds__(256) vc_compact_segments_kernel(const uint64_t* __restrict__ ring, uint32_t cap,
+                                                                  const uint64_t* __restrict__ offs,
+                                                                  uint64_t* __restrict__ out, uint64_t out_cap) {
+  const uint32_t q = blockIdx.x;
+  const uint64_t lo = offs[q], n = offs[q + 1] - offs[q];
+  for (uint64_t i = threadIdx.x; i < n && i < cap; i += blockDim.x)
+    if (lo + i < out_cap) out[lo + i] = ring[(uint64_t)q * cap + i];
 }
 
 }  // namespace
@@ -741,7 +1305,7 @@ static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, MihState* st, s
     MIH_CHECK(hipMalloc(&ix->d_tile, bytes));
     ix->tile_bytes = bytes;
   }
-  if (!ix->d_lists) MIH_CHECK(hipMalloc((void**)&ix->d_lists, (3 * Q + 4) * 4));
+  if (!ix->d_lists) MIH_CHECK(hipMalloc((void**)&ix->d_lists, (4 * Q + 4) * 4));
   uint8_t* b = (uint8_t*)ix->d_tile;
   st->thresh = (uint64_t*)(b + o_thresh);
   st->ring = (uint64_t*)(b + o_ring);
@@ -768,11 +1332,44 @@ static hipError_t launch_probe(const ProbeParams& p, uint32_t W, uint32_t n_list
   return hipGetLastError();
 }
 
+static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits) {
+  return (size_t)buf_entries * 8 + (size_t)(3 * MQ_HMAX + 1) * 4 + (size_t)33 * MQ_BW * 4 + (sbits == 32 ? (size_t)m * 32 * 4 : 0) + 16;
+}
+
+static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s) {
+  const size_t lds = query_kernel_lds(p.buf_entries, p.m, p.sbits);
+  switch (W) {
+    case 1: hipLaunchKernelGGL(mih_query_kernel<1>, dim3(nq), dim3(MQ_BLK), lds, s, p); break;
+    case 2: hipLaunchKernelGGL(mih_query_kernel<2>, dim3(nq), dim3(MQ_BLK), lds, s, p); break;
+    case 4: hipLaunchKernelGGL(mih_query_kernel<4>, dim3(nq), dim3(MQ_BLK), lds, s, p); break;
+    case 8: hipLaunchKernelGGL(mih_query_kernel<8>, dim3(nq), dim3(MQ_BLK), lds, s, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 static uint32_t binom_host(uint32_t n, uint32_t k) {
   uint64_t r = 1;
   for (uint32_t i = 1; i <= k; ++i) r = r * (n - k + i) / i;
   return (uint32_t)r;
 }
+
+// last shell the one-block-per-query kernel runs: the shells beyond cost more than `budget` bucket probes per query
+// and go to the multi-block kernels (one launch sequence per shell)
+static uint32_t inblock_last_shell(uint32_t S, uint32_t m, uint64_t budget, uint32_t r_cap) {
+  uint64_t tot = 0;
+  uint32_t r_last = 0;
+  for (uint32_t r = 0; r <= std::min(S, r_cap); ++r) {
+    const uint64_t c = (uint64_t)m * binom_host(S, r);
+    if (r > 0 && tot + c > budget) break;
+    tot += c;
+    r_last = r;
+  }
+  return std::min(r_last, 16u);
+}
+
+#define MQ_KNN_BUDGET 600000ull        // probes per query run inside mih_query_kernel (32-bit substrings, m = 4: shells 0..4)
+#define MQ_RADIUS_BUDGET 4000000ull
 
 int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint64_t n, const uint64_t* d_q, uint32_t nq,
                   uint32_t k, bool approximate, uint64_t* d_out, uint32_t* d_cnt, vc_query_stats* stats, hipStream_t s,
@@ -789,17 +1386,46 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   const uint32_t stop_mult = (ix->flags & VC_FLAG_REF_STOP_LITERAL4) ? 4u : std::min(ix->m, 4u);
   MihState st;
   if ((rc = ensure_tile(ix, k, cap, &st, err))) return rc;
-  uint32_t* lists[3] = {ix->d_lists, ix->d_lists + MIH_QTILE, ix->d_lists + 2 * MIH_QTILE};
-  uint32_t* d_ctr = ix->d_lists + 3 * MIH_QTILE;
+  uint32_t* lists[4] = {ix->d_lists, ix->d_lists + MIH_QTILE, ix->d_lists + 2 * MIH_QTILE, ix->d_lists + 3 * MIH_QTILE};
+  uint32_t* d_ctr = ix->d_lists + 4 * MIH_QTILE;
+  if (!ix->h_ctr) MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 16, hipHostMallocDefault));   // pageable memory makes the read-back a staged copy
+  uint32_t* h_ctr = ix->h_ctr;
+
+  // Shells 0..r_last run inside ONE launch, one block per query (mih_query_kernel); the host reads ONE counter per
+  // tile (how many queries are not finished) and only those continue shell by shell through the multi-block kernels.
+  uint32_t buf_entries = 1024;
+  while (buf_entries < k + MQ_ROUND) buf_entries <<= 1;
+  const bool inblock = ix->knobs.mih_host_loop == 0 && buf_entries <= 8192 && ix->m <= 64;
+  const uint32_t r_last = inblock_last_shell(S, ix->m, MQ_KNN_BUDGET, S);
+  const bool trace = ix->knobs.mih_trace;   // VC_MIH_TRACE: per-shell wall times on stderr
 
   for (uint32_t q0 = 0; q0 < nq; q0 += MIH_QTILE) {
     const uint32_t qt = std::min(MIH_QTILE, nq - q0);
     uint32_t *cur = lists[0], *nxt = lists[1], *redo = lists[2];
-    hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, cur, (uint64_t)VC_PACK_INF);
-    MIH_CHECK(hipGetLastError());
-    uint32_t n_cur = qt;
-    const bool trace = ix->knobs.mih_trace;   // VC_MIH_TRACE: per-shell wall times on stderr
-    for (uint32_t r = 0; r <= S && n_cur; ++r) {       // search_worker.cc:170: radius <= n_local_bytes_*8
+    uint32_t n_cur = qt, r_start = 0, n_heavy = qt;
+    if (inblock) {
+      QueryKernelParams qp{};
+      qp.cols = d_cols; qp.stride = stride; qp.n = ix->n; qp.tables = ix->d_tables; qp.queries = d_q + (size_t)q0 * ix->W;
+      qp.st = st; qp.m = ix->m; qp.sbits = S; qp.id_base = ix->id_base; qp.flags = ix->flags; qp.cap = cap; qp.k = k;
+      qp.mode = approximate ? MQ_MODE_APPROX : MQ_MODE_EXACT; qp.stop_mult = stop_mult; qp.r_last = r_last;
+      qp.buf_entries = buf_entries; qp.heavy_list = cur; qp.heavy_ctr = d_ctr + 2;
+      qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0;
+      const auto t_q = std::chrono::steady_clock::now();
+      MIH_CHECK(hipMemsetAsync(d_ctr, 0, 16, s));
+      MIH_CHECK(launch_query_kernel(qp, ix->W, qt, s));
+      MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 4, hipMemcpyDeviceToHost, s));
+      MIH_CHECK(hipStreamSynchronize(s));
+      n_heavy = n_cur = h_ctr[2];
+      r_start = r_last + 1;
+      if (trace)
+        fprintf(stderr, "[vc_mih] shells 0..%u in one launch: %u queries, %u continue  %.1f us\n", r_last, qt, n_cur,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_q).count());
+      if (n_heavy) MIH_CHECK(hipMemcpyAsync(lists[3], cur, (size_t)n_heavy * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+      hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, cur, (uint64_t)VC_PACK_INF);
+      MIH_CHECK(hipGetLastError());
+    }
+    for (uint32_t r = r_start; r <= S && n_cur; ++r) {       // search_worker.cc:170: radius <= n_local_bytes_*8
       const auto t_shell = std::chrono::steady_clock::now();
       ProbeParams p{};
       p.cols = d_cols; p.stride = stride; p.tables = ix->d_tables; p.queries = d_q + (size_t)q0 * ix->W;
@@ -808,11 +1434,9 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       CommitParams c{};
       c.st = st; c.next_list = nxt; c.redo_list = redo; c.ctr = d_ctr; c.k = k; c.cap = cap; c.r = r; c.sbits = S;
       c.stop_mult = stop_mult; c.approximate = approximate; c.last_shell = r == S;
-      MIH_CHECK(hipMemsetAsync(d_ctr, 0, 16, s));
+      MIH_CHECK(hipMemsetAsync(d_ctr, 0, 8, s));
       const uint32_t* work = cur;
       uint32_t n_work = n_cur;
-      if (!ix->h_ctr) MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 16, hipHostMallocDefault));   // pageable memory makes the 8-byte read-back a staged copy
-      uint32_t* h_ctr = ix->h_ctr;
       h_ctr[0] = h_ctr[1] = 0;
       for (int round = 0;; ++round) {
         p.list = work;
@@ -843,8 +1467,12 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       n_cur = h_ctr[0];
       std::swap(cur, nxt);
     }
-    hipLaunchKernelGGL(mih_export_kernel, dim3(qt), dim3(256), 0, s, st, qt, k, cap, d_out + (size_t)q0 * k, d_cnt + q0);
-    MIH_CHECK(hipGetLastError());
+    // rows of the queries that went through the multi-block shells (the query kernel wrote the others itself)
+    if (n_heavy) {
+      hipLaunchKernelGGL(mih_export_kernel, dim3(n_heavy), dim3(256), 0, s, st, inblock ? (const uint32_t*)lists[3] : (const uint32_t*)nullptr, k, cap,
+                         d_out + (size_t)q0 * k, d_cnt + q0);
+      MIH_CHECK(hipGetLastError());
+    }
     if (stats) {
       std::vector<unsigned long long> seen(qt), sub(qt), loc(qt);
       std::vector<uint32_t> rad(qt);
@@ -870,156 +1498,195 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
 // ---- fixed-radius neighbour search (BASELINE config 2) ----------------------------------------------------
 void vc_radius_work_free(VcRadiusWork* w) {
   if (!w) return;
-  (void)hipFree(w->d_ring); (void)hipFree(w->d_sorted); (void)hipFree(w->d_compact); (void)hipFree(w->d_aux); (void)hipFree(w->d_temp);
+  (void)hipFree(w->d_ring); (void)hipFree(w->d_compact); (void)hipFree(w->d_aux); (void)hipFree(w->d_offs);
+  if (w->h_tot) (void)hipHostFree(w->h_tot);
   *w = VcRadiusWork();
 }
 
-int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W,
-                     uint32_t id_base, uint32_t n_cu, const uint64_t* d_q, uint32_t nq, uint32_t radius, uint64_t* out,
-                     uint64_t out_cap, uint64_t* out_offsets, VcRadiusWork* wk, hipStream_t s, std::string* err) {
-  if (use_mih && n != ix->n) {
-    if (err) *err = "index is stale: codes were added after vc_build_index()";
-    return VC_ERR_STATE;
-  }
+// All items within full distance <= radius of each query, ascending per query, written to d_out (device memory,
+// out_cap entries) with d_offsets[nq + 1] (device).  Everything is enqueued on `s`; the host synchronises ONCE at the
+// end to learn the total and whether a query outgrew its ring (then the ring is doubled and the call repeated).
+// *total = entries needed (may exceed out_cap: VC_ERR_CAPACITY, offsets valid).
+static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W,
+                                uint32_t id_base, uint32_t n_cu, const VcKnobs* knobs, const uint64_t* d_q, uint32_t nq,
+                                uint32_t radius, uint64_t* d_out, uint64_t out_cap, uint64_t* d_offsets, uint64_t* total,
+                                VcRadiusWork* wk, hipStream_t s, std::string* err) {
   int rc;
   if (use_mih && (rc = upload_binom(err))) return rc;
   const uint32_t bits = W * 64;
   if (radius > bits) radius = bits;
+  // pigeonhole: dist <= R implies some substring within floor(R/m) (search_R_neighbors shells, search_worker.cc:222-227)
+  const uint32_t rsub = use_mih ? std::min(ix->sbits, radius / ix->m) : 0;
+  bool inblock = false;
+  if (use_mih && ix->knobs.mih_host_loop == 0) {
+    uint64_t probes = 0;
+    for (uint32_t r = 0; r <= rsub; ++r) probes += (uint64_t)ix->m * binom_host(ix->sbits, r);
+    inblock = probes <= MQ_RADIUS_BUDGET && rsub <= 16;
+  }
   const uint32_t TQ = use_mih ? MIH_QTILE : 64u;
   uint32_t cap = std::max(wk->cap, use_mih ? std::max(ix->cap, 4096u) : 65536u);
-  if (wk->tq != TQ) {   // tile shape changed (scan <-> MIH): start over with fresh buffers
-    vc_radius_work_free(wk);
-    wk->tq = TQ;
-  }
-  std::vector<uint64_t> result;
-  std::vector<uint64_t> offs(nq + 1, 0);
-
-  // work buffers live in *wk across calls (references so the retry logic below can replace them)
-  uint64_t*& d_ring = wk->d_ring;
-  uint64_t*& d_sorted = wk->d_sorted;
-  uint64_t*& d_compact = wk->d_compact;
-  uint64_t& compact_cap = wk->compact_cap;
-  uint32_t*& d_aux = wk->d_aux;     // count[TQ] | tau[TQ] | beg[TQ] | end[TQ] | hist[TQ*hs]
-  void*& d_temp = wk->d_temp;
-  size_t& temp_bytes = wk->temp_bytes;
-  if (wk->cap != cap) {             // ring size changed: both rings and the sort workspace are re-made below
-    (void)hipFree(d_ring); (void)hipFree(d_sorted);
-    d_ring = d_sorted = nullptr;
-  }
-  auto cleanup = [&]() {};          // buffers stay with the engine
+  while (cap & (cap - 1)) cap += cap & (0u - cap);   // power of two: the in-place segment sort pads to one
 #define R_CHECK(call)                                                      \
   do {                                                                     \
     hipError_t _r = (call);                                                \
     if (_r != hipSuccess) {                                                \
       if (err) *err = std::string(#call) + ": " + hipGetErrorString(_r);   \
-      cleanup();                                                           \
       return _r == hipErrorOutOfMemory ? VC_ERR_NOMEM : VC_ERR_HIP;        \
     }                                                                      \
   } while (0)
 
   const uint32_t hs = (bits + 1 + 7) & ~7u;
-  if (wk->aux_words < (size_t)TQ * (4 + hs)) {
-    (void)hipFree(d_aux);
-    d_aux = nullptr;
-    R_CHECK(hipMalloc((void**)&d_aux, (size_t)TQ * (4 + hs) * 4));
-    wk->aux_words = (size_t)TQ * (4 + hs);
+  const size_t aux_words = (size_t)TQ * (3 + hs) + 8;   // count[TQ] | tau[TQ] | sorted[TQ] | hist[TQ*hs] | tot (2 x u64)
+  if (wk->aux_words < aux_words) {
+    (void)hipFree(wk->d_aux);
+    wk->d_aux = nullptr;
+    R_CHECK(hipMalloc((void**)&wk->d_aux, aux_words * 4));
+    wk->aux_words = aux_words;
   }
-  uint32_t* d_count = d_aux;
-  uint32_t* d_tau = d_aux + TQ;
-  uint32_t* d_beg = d_aux + 2 * TQ;
-  uint32_t* d_end = d_aux + 3 * TQ;
-  uint32_t* d_hist = d_aux + 4 * TQ;
+  if (!wk->h_tot) R_CHECK(hipHostMalloc((void**)&wk->h_tot, 16, hipHostMallocDefault));
+  uint32_t* d_count = wk->d_aux;
+  uint32_t* d_tau = wk->d_aux + TQ;
+  uint32_t* d_sorted = wk->d_aux + 2 * TQ;
+  uint32_t* d_hist = wk->d_aux + 3 * TQ;
+  unsigned long long* d_tot = (unsigned long long*)(wk->d_aux + (((size_t)TQ * (3 + hs) + 1) & ~(size_t)1));
   MihState st{};
-  std::vector<uint32_t> h_count(TQ);
 
-  for (uint32_t q0 = 0; q0 < nq; q0 += TQ) {
-    const uint32_t qt = std::min(TQ, nq - q0);
-    for (;;) {  // retry with a larger ring until every query's neighbours fit
-      if (!d_ring) {
-        R_CHECK(hipMalloc((void**)&d_ring, (size_t)TQ * cap * 8));
-        R_CHECK(hipMalloc((void**)&d_sorted, (size_t)TQ * cap * 8));
-        wk->cap = cap;
-        temp_bytes = 0;
-        R_CHECK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, temp_bytes, d_ring, d_sorted, (int64_t)TQ * cap, (int)TQ,
-                                                           d_beg, d_end, 0, 44, s));
-        (void)hipFree(d_temp);
-        d_temp = nullptr;
-        R_CHECK(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 256)));
-      }
+  for (int attempt = 0;; ++attempt) {
+    if (wk->cap != cap || !wk->d_ring) {
+      (void)hipFree(wk->d_ring);
+      wk->d_ring = nullptr;
+      R_CHECK(hipMalloc((void**)&wk->d_ring, (size_t)TQ * cap * 8));
+      wk->cap = cap;
+    }
+    R_CHECK(hipMemsetAsync(d_tot, 0, 16, s));
+    for (uint32_t q0 = 0; q0 < nq; q0 += TQ) {
+      const uint32_t qt = std::min(TQ, nq - q0);
+      const uint32_t* sorted_flag = nullptr;
       if (use_mih) {
-        if ((rc = ensure_tile(ix, 1, 1, &st, err))) { cleanup(); return rc; }
-        st.ring = d_ring;   // radius search keeps every neighbour: use the big ring instead of the tile's
+        if ((rc = ensure_tile(ix, 1, 1, &st, err))) return rc;
+        st.ring = wk->d_ring;   // radius search keeps every neighbour: the big ring instead of the tile's
         st.count = d_count;
-        uint32_t* list = ix->d_lists;
-        hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, list, vc_pack(radius + 1, 0));
-        R_CHECK(hipGetLastError());
-        // pigeonhole: dist <= R implies some substring within floor(R/m) (search_R_neighbors shells, search_worker.cc:222-227)
-        const uint32_t rmax = std::min(ix->sbits, radius / ix->m);
-        for (uint32_t r = 0; r <= rmax; ++r) {
-          ProbeParams p{};
-          p.cols = d_cols; p.stride = stride; p.tables = ix->d_tables; p.queries = d_q + (size_t)q0 * W; p.list = list;
-          p.st = st; p.r = r; p.nkeys = binom_host(ix->sbits, r); p.m = ix->m; p.sbits = ix->sbits; p.id_base = id_base;
-          p.flags = ix->flags; p.cap = cap; p.count_seen = 1; p.n = ix->n;
-          R_CHECK(launch_probe(p, W, qt, s));
+        st.topn = d_sorted;
+        if (inblock) {
+          QueryKernelParams qp{};
+          qp.cols = d_cols; qp.stride = stride; qp.n = ix->n; qp.tables = ix->d_tables; qp.queries = d_q + (size_t)q0 * W;
+          qp.st = st; qp.m = ix->m; qp.sbits = ix->sbits; qp.id_base = id_base; qp.flags = ix->flags; qp.cap = cap; qp.k = 0;
+          qp.mode = MQ_MODE_RADIUS; qp.radius = radius; qp.r_last = rsub; qp.buf_entries = 2048;
+          R_CHECK(launch_query_kernel(qp, W, qt, s));
+          sorted_flag = d_sorted;
+        } else {
+          uint32_t* list = ix->d_lists;
+          hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, list, vc_pack(radius + 1, 0));
+          R_CHECK(hipGetLastError());
+          for (uint32_t r = 0; r <= rsub; ++r) {
+            ProbeParams p{};
+            p.cols = d_cols; p.stride = stride; p.tables = ix->d_tables; p.queries = d_q + (size_t)q0 * W; p.list = list;
+            p.st = st; p.r = r; p.nkeys = binom_host(ix->sbits, r); p.m = ix->m; p.sbits = ix->sbits; p.id_base = id_base;
+            p.flags = ix->flags; p.cap = cap; p.count_seen = 1; p.n = ix->n;
+            R_CHECK(launch_probe(p, W, qt, s));
+          }
         }
       } else {
-        R_CHECK(hipMemsetAsync(d_aux, 0, (size_t)TQ * (4 + hs) * 4, s));
+        R_CHECK(hipMemsetAsync(wk->d_aux, 0, (size_t)TQ * (3 + hs) * 4, s));
         hipLaunchKernelGGL(vc_fill_u32_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, d_tau, qt, radius);
         R_CHECK(hipGetLastError());
         size_t lds;
-        const VcScanShape sh = vc_scan_pick_shape(W, qt, &lds, nullptr);
+        const VcScanShape sh = vc_scan_pick_shape(W, qt, &lds, knobs);
         VcScanParams p{};
         p.cols = d_cols; p.stride = stride; p.n = n; p.nchunks = (n + sh.chunk_items() - 1) / sh.chunk_items();
         p.id_base = id_base; p.qt = qt; p.k = 0xFFFFFFFFu;   // never re-derive tau: it is the fixed radius
         p.cap = cap; p.hist_stride = hs; p.queries = d_q + (size_t)q0 * W; p.tau = d_tau; p.count = d_count; p.qs = 1;
-        p.hist = d_hist; p.buf = d_ring;
-        R_CHECK(vc_launch_scan(p, W, n_cu, 0, nullptr, s));
+        p.hist = d_hist; p.buf = wk->d_ring;
+        R_CHECK(vc_launch_scan(p, W, n_cu, 0, knobs, s));
       }
-      R_CHECK(hipMemcpyAsync(h_count.data(), d_count, qt * 4, hipMemcpyDeviceToHost, s));
-      R_CHECK(hipStreamSynchronize(s));
-      uint32_t mx = 0;
-      for (uint32_t i = 0; i < qt; ++i) mx = std::max(mx, h_count[i]);
-      if (mx <= cap) break;
-      uint64_t want = 1;
-      while (want < mx) want <<= 1;
-      if (want * TQ * 16 > (64ull << 30)) {
-        if (err) *err = "radius search: a query has more neighbours than the work ring can hold";
-        cleanup();
-        return VC_ERR_CAPACITY;
-      }
-      cap = (uint32_t)want;
-      (void)hipFree(d_ring); (void)hipFree(d_sorted);
-      d_ring = d_sorted = nullptr;
-    }
-    hipLaunchKernelGGL(vc_seg_bounds_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, d_count, qt, cap, d_beg, d_end);
-    R_CHECK(hipGetLastError());
-    R_CHECK(hipcub::DeviceSegmentedRadixSort::SortKeys(d_temp, temp_bytes, d_ring, d_sorted, (int64_t)qt * cap, (int)qt, d_beg, d_end,
-                                                       0, 44, s));
-    for (uint32_t i = 0; i < qt; ++i) offs[q0 + i + 1] = offs[q0 + i] + h_count[i];
-    const uint64_t tile_total = offs[q0 + qt] - offs[q0];
-    if (tile_total) {   // gather the tile's segments on the device, one copy back
-      if (tile_total > compact_cap) {
-        (void)hipFree(d_compact);
-        d_compact = nullptr;
-        compact_cap = tile_total * 2;
-        R_CHECK(hipMalloc((void**)&d_compact, compact_cap * 8 + (TQ + 1) * 8));
-      }
-      uint64_t* d_offs = d_compact + compact_cap;
-      R_CHECK(hipMemcpyAsync(d_offs, offs.data() + q0, (size_t)(qt + 1) * 8, hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(vc_compact_segments_kernel, dim3(qt), dim3(256), 0, s, d_sorted, cap, d_offs, qt, d_compact);
+      // order every segment (hand-written bitonic network; the query kernel's small segments arrive sorted), place the
+      // tile's segments behind the previous tiles' and copy them out
+      hipLaunchKernelGGL(vc_sort_segments_kernel, dim3(qt), dim3(1024), 0, s, wk->d_ring, cap, d_count, sorted_flag);
       R_CHECK(hipGetLastError());
-      const size_t base = result.size();
-      result.resize(base + tile_total);
-      R_CHECK(hipMemcpyAsync(result.data() + base, d_compact, tile_total * 8, hipMemcpyDeviceToHost, s));
-      R_CHECK(hipStreamSynchronize(s));
+      hipLaunchKernelGGL(vc_radius_offsets_kernel, dim3(1), dim3(1024), 0, s, d_count, qt, d_offsets + q0, d_tot);
+      R_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(vc_compact_segments_kernel, dim3(qt), dim3(256), 0, s, wk->d_ring, cap, d_offsets + q0, d_out, out_cap);
+      R_CHECK(hipGetLastError());
     }
+    R_CHECK(hipMemcpyAsync(wk->h_tot, d_tot, 16, hipMemcpyDeviceToHost, s));
+    R_CHECK(hipStreamSynchronize(s));
+    const uint64_t mx = wk->h_tot[1];
+    *total = wk->h_tot[0];
+    if (mx <= cap) break;
+    uint64_t want = cap;
+    while (want < mx) want <<= 1;
+    if (attempt > 8 || want * TQ * 8 > (64ull << 30)) {
+      if (err) *err = "radius search: a query has more neighbours than the work ring can hold";
+      return VC_ERR_CAPACITY;
+    }
+    cap = (uint32_t)want;
   }
 #undef R_CHECK
-  memcpy(out_offsets, offs.data(), (nq + 1) * sizeof(uint64_t));
-  if (offs[nq] > out_cap) {
+  if (*total > out_cap) {
     if (err) *err = "radius search: output buffer too small (needed counts are in out_offsets)";
     return VC_ERR_CAPACITY;
   }
-  if (offs[nq]) memcpy(out, result.data(), offs[nq] * sizeof(uint64_t));
+  return VC_OK;
+}
+
+int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W,
+                     uint32_t id_base, uint32_t n_cu, const VcKnobs* knobs, const uint64_t* d_q, uint32_t nq, uint32_t radius,
+                     uint64_t* out, uint64_t out_cap, uint64_t* out_offsets, bool device_out, VcRadiusWork* wk, hipStream_t s,
+                     std::string* err) {
+  if (use_mih && n != ix->n) {
+    if (err) *err = "index is stale: codes were added after vc_build_index()";
+    return VC_ERR_STATE;
+  }
+  const uint32_t TQ = use_mih ? MIH_QTILE : 64u;
+  if (wk->tq != TQ) {   // tile shape changed (scan <-> MIH): start over with fresh buffers
+    vc_radius_work_free(wk);
+    wk->tq = TQ;
+  }
+  if (device_out) {
+    uint64_t total = 0;
+    return radius_search_device(ix, use_mih, d_cols, stride, n, W, id_base, n_cu, knobs, d_q, nq, radius, out, out_cap, out_offsets,
+                                &total, wk, s, err);
+  }
+  // host-pointer API: stage in device memory, grow the staging buffer to what the call needs, one copy back
+  if (wk->offs_cap < (size_t)nq + 1) {
+    (void)hipFree(wk->d_offs);
+    wk->d_offs = nullptr;
+    if (hipMalloc((void**)&wk->d_offs, ((size_t)nq + 1) * 8) != hipSuccess) {
+      if (err) *err = "radius search: offsets allocation failed";
+      return VC_ERR_NOMEM;
+    }
+    wk->offs_cap = (size_t)nq + 1;
+  }
+  uint64_t total = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (!wk->d_compact) {
+      if (wk->compact_cap == 0) wk->compact_cap = std::max<uint64_t>(out_cap, 1u << 16);
+      if (hipMalloc((void**)&wk->d_compact, wk->compact_cap * 8) != hipSuccess) {
+        if (err) *err = "radius search: staging allocation failed";
+        return VC_ERR_NOMEM;
+      }
+    }
+    std::string e2;
+    int rc = radius_search_device(ix, use_mih, d_cols, stride, n, W, id_base, n_cu, knobs, d_q, nq, radius, wk->d_compact, wk->compact_cap,
+                                  wk->d_offs, &total, wk, s, &e2);
+    if (rc == VC_OK) break;
+    if (rc != VC_ERR_CAPACITY || total <= wk->compact_cap || pass == 1) {
+      if (err) *err = e2;
+      return rc;
+    }
+    (void)hipFree(wk->d_compact);   // the staging buffer was too small: now the needed size is known
+    wk->d_compact = nullptr;
+    wk->compact_cap = total * 2;
+  }
+  if (hipMemcpyAsync(out_offsets, wk->d_offs, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      (total <= out_cap && total && hipMemcpyAsync(out, wk->d_compact, total * 8, hipMemcpyDeviceToHost, s) != hipSuccess) ||
+      hipStreamSynchronize(s) != hipSuccess) {
+    if (err) *err = "radius search: copy back failed";
+    return VC_ERR_HIP;
+  }
+  if (total > out_cap) {
+    if (err) *err = "radius search: output buffer too small (needed counts are in out_offsets)";
+    return VC_ERR_CAPACITY;
+  }
   return VC_OK;
 }

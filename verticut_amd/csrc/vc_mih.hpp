@@ -19,16 +19,20 @@ int vc_mih_bitmap_read(VcMihIndex* ix, uint32_t table, uint64_t word_off, uint64
                        std::string* err);
 // grow-only device buffers of the radius search, owned by the engine (allocation costs more than a search)
 struct VcRadiusWork {
-  uint64_t *d_ring = nullptr, *d_sorted = nullptr, *d_compact = nullptr;
+  uint64_t *d_ring = nullptr, *d_compact = nullptr, *d_offs = nullptr;
   uint32_t* d_aux = nullptr;
-  void* d_temp = nullptr;
-  size_t temp_bytes = 0, aux_words = 0;
+  unsigned long long* h_tot = nullptr;   // pinned: total entries and largest segment of a call
+  size_t aux_words = 0, offs_cap = 0;
   uint64_t compact_cap = 0;
   uint32_t cap = 0, tq = 0;
 };
 void vc_radius_work_free(VcRadiusWork* w);
 
-// all items within full distance <= radius; ix may be null when use_mih is false (linear scan)
+// All items within full distance <= radius, ascending per query; ix may be null when use_mih is false (linear scan).
+// device_out = false: out / out_offsets are host memory (staged through the engine's buffers);
+// device_out = true : out (out_cap entries) / out_offsets (nq + 1) are device memory, everything is enqueued on `s`
+// and the host synchronises once at the end.
 int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W,
-                     uint32_t id_base, uint32_t n_cu, const uint64_t* d_q, uint32_t nq, uint32_t radius, uint64_t* out,
-                     uint64_t out_cap, uint64_t* out_offsets, VcRadiusWork* work, hipStream_t s, std::string* err);
+                     uint32_t id_base, uint32_t n_cu, const VcKnobs* knobs, const uint64_t* d_q, uint32_t nq, uint32_t radius,
+                     uint64_t* out, uint64_t out_cap, uint64_t* out_offsets, bool device_out, VcRadiusWork* work, hipStream_t s,
+                     std::string* err);

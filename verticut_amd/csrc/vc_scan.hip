@@ -555,25 +555,6 @@ struct VcListsSrc {
 #define VC_SEL_THREADS 1024
 #define VC_RANK_SORT_MAX 1024u
 
-__device__ __forceinline__ void vc_bitonic_lds(uint64_t* a, uint32_t P, uint32_t nthreads = VC_SEL_THREADS) {
-  for (uint32_t size = 2; size <= P; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      for (uint32_t i = threadIdx.x; i < (P >> 1); i += nthreads) {
-        const uint32_t lo = 2 * i - (i & (stride - 1));
-        const uint32_t hi = lo + stride;
-        const uint64_t x = a[lo], y = a[hi];
-        const bool up = (lo & size) == 0;
-        if ((x > y) == up) {
-          a[lo] = y;
-          a[hi] = x;
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
-
 template <class Src>
 __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint32_t k, uint64_t* __restrict__ out,
                                                                    uint32_t* __restrict__ out_count) {
@@ -735,7 +716,7 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
     __syncthreads();
     sorted = srt;
   } else {
-    vc_bitonic_lds(a, P);
+    vc_bitonic_lds(a, P, VC_SEL_THREADS);
   }
   if (threadIdx.x == 0) s_valid = 0;
   __syncthreads();

@@ -27,6 +27,7 @@ EXPORTS = [
     "vc_size", "vc_get_code", "vc_build_index", "vc_get_bucket", "vc_bitmap_test", "vc_bitmap_read", "vc_search_knn",
     "vc_search_knn_dev", "vc_search_radius", "vc_merge_topk_dev", "vc_get_timing", "vc_set_stream",
     "vc_load_code_file", "vc_save_code_file", "vc_write_bitmap_file", "vc_device_status",
+    "vc_search_radius_dev",
 ]
 
 
@@ -96,6 +97,7 @@ def load_library():
     L.vc_search_knn.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]
     L.vc_search_knn_dev.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp]
     L.vc_search_radius.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp]
+    L.vc_search_radius_dev.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp, vp]
     L.vc_merge_topk_dev.argtypes = [vp, u32, u32, u32, vp, vp, vp]
     L.vc_load_code_file.argtypes = [vp, C.c_char_p, u64, C.POINTER(u64)]
     L.vc_save_code_file.argtypes = [vp, C.c_char_p]
@@ -258,6 +260,11 @@ class Engine:
                 return [out[int(offs[i]):int(offs[i + 1])].copy() for i in range(nq)]
             cap = int(offs[nq])
         raise VcError(VC_ERR_CAPACITY, "radius search output does not fit")
+
+    def search_radius_dev(self, d_queries, nq, radius, d_out, out_cap, d_offsets, mode=MODE_MIH_EXACT, stream=None):
+        """Device-pointer radius search (raw device addresses); returns VC_OK or VC_ERR_CAPACITY (d_offsets[nq] = needed)."""
+        return self._check(self._L.vc_search_radius_dev(self._h, d_queries, nq, radius, mode, d_out, out_cap, d_offsets, stream),
+                           ok=(VC_OK, VC_ERR_CAPACITY))
 
     def timing(self):
         t = VcTiming()
