@@ -7,17 +7,24 @@ One step = one batch of Q queries verified against the whole database by the HBM
 result buffers are resident in HBM before the timed region starts.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (achieved HBM GB/s of the
-verify kernel from HIP events recorded on its stream, against the 8 TB/s peak) and `cpu_baseline` (the CPU
-restatement of linear_search.cc timed on this host on a bounded sample).
+verify kernel from HIP events recorded on its stream, against the 8 TB/s peak; `traffic` = HBM bytes per launch from
+a rocprofv3 --pmc pass of a short child run of this same script) and `cpu_baseline` (the CPU restatement of the
+reference path timed on this host on a bounded sample).
 
-    python bench.py                               # 1 GPU, 1e9 codes
+    python bench.py                               # 1 GPU, 1e9 codes: the headline line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --workload c2                 # BASELINE configs[1]: 64-bit, 1e8 codes, MIH radius-8 search (m = 2; m = 4 as a variant)
+    python bench.py --workload c5shard            # one GPU's share of configs[4]: 256-bit, 5e8 codes, 4096 queries per pass
+    python bench.py --workload knn_mih            # exact top-100 through MIH on 1e8 clustered 128-bit codes
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,25 +33,44 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a pure copy reaches)
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a pure copy reaches)
+VALU_PEAK_GOPS = 39321.6  # 256 CUs x 64 lanes x 2.4 GHz 32-bit lane-ops/s; v_xor issues at ~2.3 and
+#                           v_bcnt at ~4.2 cycles per wave64 instruction per SIMD, so the xor+popcount mix tops out near 0.6 of it
+METRIC = "queries/sec (k-NN top-100) on 128-bit codes, 1B DB; bit-exact vs linear_search"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--db-size", dest="n", type=float, default=1e9, help="database size (total over all GPUs)")
-    ap.add_argument("--bits", type=int, default=128)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5shard", "knn_mih"],
+                    help="c3 = the headline (BASELINE configs[2]/[3]); the others are extra lines, same JSON shape")
+    ap.add_argument("--db-size", dest="n", type=float, default=None, help="database size (total over all GPUs)")
+    ap.add_argument("--bits", type=int, default=None)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--queries", type=int, default=8, help="queries per step (= one query tile = one DB pass)")
+    ap.add_argument("--queries", type=int, default=None, help="queries per step")
     ap.add_argument("--seed", type=int, default=34, help="linear_search.cc:105 srand(34)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child run that measures roofline.traffic")
+    args = ap.parse_args(argv)
+    d = {"c3": (1e9, 128, 8, 30), "c2": (1e8, 64, 1024, 20), "c5shard": (5e8, 256, 4096, 4), "knn_mih": (1e8, 128, 4096, 10)}[args.workload]
+    if args.n is None:
+        args.n = d[0]
+    if args.bits is None:
+        args.bits = d[1]
+    if args.queries is None:
+        args.queries = d[2]
+    if args.steps is None:
+        args.steps = d[3]
+    return args
 
 
-def cpu_baseline(args, n_total):
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (the only place bench.py touches oracle/, outside every timed GPU region)
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline_linear(args, n_total):
     """linear_search.cc:39-64 restated (oracle/vc_oracle.cc vco_linear_knn_ref: 32-bit popcount loop +
     std::priority_queue), 1 thread, in-memory codes, on a bounded sample of the same synthetic database;
     scaled to the full database size (the scan is exactly linear in N)."""
@@ -61,10 +87,12 @@ def cpu_baseline(args, n_total):
         done += 1
     dt = time.perf_counter() - t0
     qps_sample = done / dt
+    nproc = os.cpu_count() or 1
     res = {
         "value": qps_sample * sample_n / n_total,
         "unit": "queries/s",
         "cores": 1,
+        "nproc": nproc,
         "kind": "port",
         "sample": "%d queries x first %d codes of the same synthetic DB in %.1f s, 1 thread; scaled by N_sample/N "
                   "(scan cost is linear in N); structure of linear_search.cc:39-64 over in-memory codes (no KV get)"
@@ -72,119 +100,239 @@ def cpu_baseline(args, n_total):
         "items_per_s": qps_sample * sample_n,
     }
     # all host cores (BASELINE.md row CPU-linear-allcores): same scan split over threads + merge
-    cores = min(os.cpu_count() or 1, 16)   # this GPU's share of the host (one of eight GPUs on the node)
+    cores = nproc
     t0 = time.perf_counter()
     done = 0
     while done < len(q) and time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
         vo.linear_knn(codes, q[done], args.k, threads=cores)
         done += 1
     dt = time.perf_counter() - t0
-    res["allcores"] = {"value": done / dt * sample_n / n_total, "cores": cores}
+    res["allcores"] = {"value": done / dt * sample_n / n_total, "cores": cores, "nproc": nproc}
     return res
 
 
-def main():
-    args = parse()
-    # The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL writes a five-line version
-    # banner when its communicator comes up), so fd 1 is pointed at stderr for the whole run and the JSON line goes to
-    # a private duplicate of the original stdout.
-    sys.stdout.flush()
-    json_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
-    import torch
-    import torch.distributed as dist
-    from verticut_amd import engine as vc
-    from verticut_amd.sharded import ShardedSearch
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-        args.gpus = world
-    # rehearsal knobs (dev only): run the multi-rank flow on ONE GPU, where RCCL cannot be used (one device per rank)
-    backend = os.environ.get("VC_BENCH_BACKEND", "nccl")
-    if os.environ.get("VC_BENCH_ONE_GPU") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+def cpu_baseline_mih(args, m, kind, radius=None, clustered=False):
+    """search_worker.cc:159-264 restated (oracle/vc_oracle.cc: enumerate_entry per rank, gather in rank order, master-side
+    dedup + heap), one thread per table like `mpirun -n m` (run_distributed_search.py:12,74), in-memory buckets instead of
+    a KV tier, on a bounded SAMPLE database: the probe count per query does not depend on N, only the bucket sizes do,
+    so the sample flatters the CPU (fewer candidates per bucket than at full size) and is reported unscaled."""
+    from oracle import vc_oracle as vo
+    sample_n = int(min(args.n, 2_000_000 if clustered else 4_000_000))
+    t0 = time.perf_counter()
+    if clustered:
+        codes = vo.gen_codes(sample_n, args.bits, args.seed, kind=1, n_centres=max(sample_n // 1000, 1), max_flips=11)
+    else:
+        codes = vo.gen_codes(sample_n, args.bits, args.seed)
+    mo = vo.MihOracle(codes, m, key_mode=1)
+    t_build = time.perf_counter() - t0
+    rng = np.random.default_rng(4321)
+    nproc = os.cpu_count() or 1
+    threads = min(m, nproc)
+    t0 = time.perf_counter()
+    done, probes = 0, 0
+    while time.perf_counter() - t0 < args.cpu_seconds:
+        q = codes[int(rng.integers(0, sample_n))].copy()
+        for b in rng.choice(args.bits, size=int(rng.integers(0, (radius if radius is not None else 4) + 1)), replace=False):
+            q[b // 8] ^= np.uint8(1 << (b % 8))
+        if kind == "radius":
+            _, pr = mo.radius(q, radius, threads=threads)
+            probes += pr
         else:
-            dist.init_process_group(backend)
+            _, st = mo.find(q, args.k, stop_mult=min(m, 4), threads=threads)
+            probes += st.n_sub_reads_all
+        done += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": done / dt, "unit": "queries/s", "cores": threads, "nproc": nproc, "kind": "port",
+        "sample": "%d queries in %.1f s on a %d-code sample of the same synthetic DB (index build %.1f s not counted), %d threads "
+                  "= one per table; %s; NOT scaled to the full size (bucket sizes grow with N, probes per query do not: %.0f "
+                  "bucket gets per query)" % (done, dt, sample_n, t_build, threads,
+                                              "search_R_neighbors shells 0..r/m + gather + dedup (search_worker.cc:222-264)"
+                                              if kind == "radius" else "SearchWorker::find exact loop (search_worker.cc:159-218)",
+                                              probes / max(done, 1)),
+    }
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# environment: ranks, devices, process group
+# ---------------------------------------------------------------------------------------------------------------
+class Env:
+    """rank / world / device of this process and the small set of collectives the bench needs"""
+
+    def __init__(self, args, device_kind="cuda", dist_backend=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+            args.gpus = self.world
+        # rehearsal knobs (dev only): run the multi-rank flow on ONE GPU, where RCCL cannot be used (one device per rank)
+        self.backend = dist_backend or os.environ.get("VC_BENCH_BACKEND", "nccl")
+        if os.environ.get("VC_BENCH_ONE_GPU") == "1":
+            self.local_rank = 0
+        self.cuda = device_kind == "cuda"
+        if self.cuda:
+            torch.cuda.set_device(self.local_rank)
+            self.device = torch.device("cuda", self.local_rank)
+        else:
+            self.device = torch.device("cpu")
+        self.own_group = False
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.device)
+            else:
+                dist.init_process_group(self.backend)
+            self.own_group = True
+
+    def sync(self):
+        if self.cuda:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ok(self, ok):
+        if self.world == 1:
+            return ok
+        t = self.torch.tensor([1 if ok else 0], device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def close(self):
+        if self.own_group:
+            self.dist.destroy_process_group()
+
+
+def timed_steps(env, run_steps, steps):
+    """the contract's timed region: barrier + synchronize on both sides, MAX over ranks"""
+    env.barrier()
+    env.sync()
+    t0 = time.perf_counter()
+    res = run_steps(steps)
+    env.sync()
+    t1 = time.perf_counter()
+    env.barrier()
+    return res, env.max_over_ranks(t1 - t0)
+
+
+def measure_traffic(args, kernel_substr):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters of a short child run of this
+    same script under rocprofv3 (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, TCC slots; FETCH_SIZE x 2 for a
+    wide coalesced stream on gfx950 -- MI355X_MICROARCH.md, HBM section).  None when rocprofv3 is unavailable or fails."""
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None, "rocprofv3 not on PATH"
+    import csv
+    import glob
+    vals = {}
+    base = ["--workload", args.workload, "--db-size", repr(float(args.n)), "--bits", str(args.bits), "--k", str(args.k),
+            "--queries", str(args.queries), "--seed", str(args.seed), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
+            "--no-check", "--no-traffic"]
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py")] + base
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            except Exception as ex:   # noqa: BLE001 -- any failure means "not measured"
+                return None, "rocprofv3 --pmc %s child run failed: %s" % (counter, type(ex).__name__)
+            got = []
+            for f in glob.glob(os.path.join(td, "**", "*_counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, "no %s rows for %s" % (counter, kernel_substr)
+            vals[counter] = sum(got[1:]) / max(len(got) - 1, 1) if len(got) > 1 else got[0]   # drop the first (cold) launch
+    return (vals["FETCH_SIZE"] * 2 + vals["WRITE_SIZE"]) * 1024.0, \
+        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB) of a 3-step child run: FETCH_SIZE x 2 + WRITE_SIZE"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# headline: BASELINE configs[2] (1 GPU) / configs[3] (N GPUs)
+# ---------------------------------------------------------------------------------------------------------------
+def run_headline(args, env, emit, backend_factory=None):
+    torch = env.torch
+    from verticut_amd.sharded import ShardedSearch
+    world, rank = env.world, env.rank
     n_total = int(args.n)
     Q, k = args.queries, args.k
     force_exchange = world == 1 and os.environ.get("VC_BENCH_FORCE_EXCHANGE") == "1"   # dev: RCCL exchange with one rank
-    if force_exchange:
+    if force_exchange and not env.dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": device} if backend == "nccl" else {}))
+        env.dist.init_process_group(env.backend, rank=0, world_size=1, **({"device_id": env.device} if env.backend == "nccl" else {}))
+        env.own_group = True
     engine_kw = {}
     if os.environ.get("VC_BENCH_SCAN_BLOCKS"):      # dev: cap the persistent verify grid (leave block slots to other kernels)
         engine_kw["scan_blocks"] = int(os.environ["VC_BENCH_SCAN_BLOCKS"])
     # N > 1: the per-shard top-k of 8 consecutive batches share one all-gather + merge (ShardedSearch(bucket=8)): the
     # collective is latency-bound at 6.4 KB per rank, every step still ends inside the timed region (flush()).
     bucket = int(os.environ.get("VC_BENCH_BUCKET", "8")) if (world > 1 or force_exchange) else 1
-    ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=local_rank, query_tile=Q,
-                       force_exchange=force_exchange, bucket=bucket, **engine_kw)
+    if backend_factory is not None:
+        from verticut_amd.sharded import shard_range
+        lo, hi = shard_range(n_total, rank, world)
+        ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, backend=backend_factory(args.bits, lo, hi),
+                           force_exchange=force_exchange, bucket=bucket)
+    else:
+        ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=env.local_rank, query_tile=Q,
+                           force_exchange=force_exchange, bucket=bucket, **engine_kw)
     ss.add_synthetic(args.seed)
 
     # query batches resident in HBM: uniform random codes = worst case (no early threshold help)
     rng = np.random.default_rng(args.seed + 1)
     nb = 4
     host_q = [rng.integers(0, 256, size=(Q, args.bits // 8), dtype=np.uint8) for _ in range(nb)]
-    dev_q = [torch.from_numpy(h).to(device) for h in host_q]
-    torch.cuda.synchronize()
+    dev_q = [torch.from_numpy(h).to(env.device) for h in host_q]
+    env.sync()
 
     def run_steps(count):
         res = None
         for i in range(count):
             res = ss.search(dev_q[i % nb], k)
-        ss.flush()                  # N > 1, pipelined exchange: the last batches' side-stream work joins this stream
+        ss.flush()                  # N > 1: the last (partly filled) bucket is exchanged inside the timed region
         return res
 
     # Priming, part of set-up like the data generation above: the first launches after the 16 GB fill run 10-15 %
     # slow (clocks, page tables; kernel trace in profiles/), and a driver-chosen --warmup may be shorter than that.
     run_steps(8)
-    torch.cuda.synchronize()
+    env.sync()
     run_steps(args.warmup)
-    torch.cuda.synchronize()
+    env.sync()
     exchange = "none"
     if world > 1 or force_exchange:
         # The per-batch exchange (all-gather + merge) runs inline on the step's stream: the plain, widely used pattern.
         # VC_BENCH_PIPELINED=1 moves it to a side stream under the next batch's scan (ShardedSearch(pipelined=True));
         # that path is covered by tests but has never run over RCCL on a multi-GPU node, so it is opt-in.
-        ss.pipelined = os.environ.get("VC_BENCH_PIPELINED") == "1"
+        ss.pipelined = os.environ.get("VC_BENCH_PIPELINED") == "1" and env.cuda
         exchange = "side-stream" if ss.pipelined else ("inline, %d batches per all-gather" % bucket if bucket > 1 else "inline")
         if ss.pipelined:
             run_steps(2)
-            torch.cuda.synchronize()
+            env.sync()
     ss.backend.timing()  # drop warm-up event records
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out, cnt = run_steps(args.steps)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    if world > 1:
-        dist.barrier()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    (out, cnt), elapsed = timed_steps(env, run_steps, args.steps)
     tm = ss.backend.timing()  # HIP events on the launch stream, exactly the timed steps
 
     ok = True
     if not args.no_check:
         # size-independent properties of the last batch (bit-exact parity proper lives in tests/): ascending
-        # packed values, k results, every reported distance recomputed from the stored code.
+        # packed values, k results, every reported distance recomputed from the stored code, no unrecovered overflow.
         res = out.cpu().numpy().view(np.uint64)
         qh = host_q[(args.steps - 1) % nb]
         why = []
@@ -193,37 +341,31 @@ def main():
         if not np.all(res[:, 1:] > res[:, :-1]):
             why.append("rows not strictly ascending")
         for qi in range(min(Q, 2)):
-            for j in (0, k // 2, k - 1):
+            for j in range(k):                            # every result of two queries that this rank's shard holds
                 gid = int(res[qi, j] & np.uint64(0xFFFFFFFF))
                 if ss.lo <= gid < ss.hi:
-                    code = ss.backend.engine.get_code(gid)
+                    code = ss.backend.get_code(gid)
                     d = int(np.unpackbits(np.bitwise_xor(code, qh[qi])).sum())
                     if d != int(res[qi, j] >> np.uint64(32)):
                         why.append("query %d result %d: id %d reported %d, stored code says %d"
                                    % (qi, j, gid, int(res[qi, j] >> np.uint64(32)), d))
+        if ss.unrecovered():
+            why.append("device-side ring-overflow recovery gave up")
         ok = not why
         if why:
             sys.stderr.write("[bench rank %d] results check failed: %s\n" % (rank, "; ".join(why[:4])))
-        if world > 1:
-            okt = torch.tensor([1 if ok else 0], device=device)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            ok = bool(okt.item())
+        ok = env.all_ok(ok)
+    ss.close()
 
     if rank == 0:
         scan_avg_ms = tm.scan_ms / max(tm.scan_launches, 1)
         bytes_per_launch = tm.scan_bytes / max(tm.scan_launches, 1)
         achieved = bytes_per_launch / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
-        if world == 1 and os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("n_codes") == n_total and tj.get("bits") == args.bits:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_how = None, "not measured"
+        if world == 1 and env.cuda and not args.no_traffic and backend_factory is None:
+            traffic, traffic_how = measure_traffic(args, "vc_scan_kernel")
         line = {
-            "metric": "queries/sec (k-NN top-100) on 128-bit codes, 1B DB; bit-exact vs linear_search",
+            "metric": METRIC,
             "value": Q * args.steps / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
@@ -247,19 +389,261 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_how": traffic_how,
                 "kernel": "vc_scan_kernel", "launches": tm.scan_launches, "avg_launch_ms": scan_avg_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
             },
             "results_check": "ok" if ok else "FAILED",
         }
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(args, n_total)
-        json_out.write(json.dumps(line) + "\n")
-        json_out.flush()
-    ss.close()
-    if world > 1:
-        dist.destroy_process_group()
+            line["cpu_baseline"] = cpu_baseline_linear(args, n_total)
+        emit(line)
+    return ok
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# extra workloads (1 GPU): same JSON shape, never the default
+# ---------------------------------------------------------------------------------------------------------------
+def _near_queries(engine, n, nq, bits, max_flips, rng):
+    q = np.empty((nq, bits // 8), dtype=np.uint8)
+    for i in range(nq):
+        c = engine.get_code(int(rng.integers(0, n)))
+        for b in rng.choice(bits, size=int(rng.integers(0, max_flips + 1)), replace=False):
+            c[b // 8] ^= np.uint8(1 << (b % 8))
+        q[i] = c
+    return q
+
+
+def _mih_roofline(tm, bits):
+    """bytes = probes x 4 (bitmap) + non-empty buckets x 16 (key lookup) + entries x (4 id + B/8 code)"""
+    launches = max(tm.mih_launches, 1)
+    alg = (tm.mih_probes * 4 + tm.mih_hits * 16 + tm.mih_entries * (4 + bits // 8)) / launches
+    avg_ms = tm.mih_ms / launches
+    achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None, "kernel": "mih_query_kernel", "launches": tm.mih_launches, "avg_launch_ms": avg_ms,
+        "algorithmic_bytes_per_launch": alg,
+        "per_query": {"probes": tm.mih_probes / max(tm.mih_queries, 1), "non_empty_buckets": tm.mih_hits / max(tm.mih_queries, 1),
+                      "entries_verified": tm.mih_entries / max(tm.mih_queries, 1)},
+        "note": "random 4..64-byte accesses: the byte roofline is the wrong yardstick by construction (sector-granular "
+                "gathers); sector traffic from rocprofv3 is in profiles/ and DESIGN.md 4.2",
+    }
+
+
+def run_c2(args, env, emit):
+    """BASELINE configs[1]: 64-bit codes, 1e8 DB, all neighbours within distance 8 through MIH (search_worker.cc:222-264)."""
+    torch = env.torch
+    from verticut_amd import engine as vc
+    n, bits, Q, radius = int(args.n), args.bits, args.queries, 8
+    rng = np.random.default_rng(args.seed + 2)
+    lines = {}
+    for m in (2, 4):
+        e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
+        e.add_synthetic(n, seed=args.seed)
+        t0 = time.perf_counter()
+        e.build_index()
+        t_build = time.perf_counter() - t0
+        host_q = [_near_queries(e, n, Q, bits, radius, rng) for _ in range(2)]
+        dev_q = [torch.from_numpy(h).to(env.device) for h in host_q]
+        out_cap = Q * 64
+        d_out = torch.empty((out_cap,), dtype=torch.int64, device=env.device)
+        d_off = torch.empty((Q + 1,), dtype=torch.int64, device=env.device)
+        s = torch.cuda.current_stream().cuda_stream
+
+        def run_steps(count):
+            for i in range(count):
+                e.search_radius_dev(dev_q[i % 2].data_ptr(), Q, radius, d_out.data_ptr(), out_cap, d_off.data_ptr(),
+                                    mode=vc.MODE_MIH_EXACT, stream=s)
+
+        run_steps(max(args.warmup, 2))
+        env.sync()
+        e.timing()
+        _, elapsed = timed_steps(env, run_steps, args.steps)
+        tm = e.timing()
+        ok = True
+        if not args.no_check:   # MIH == full scan on the last batch (the oracle-level parity lives in tests/)
+            off = d_off.cpu().numpy().view(np.uint64)
+            res = d_out.cpu().numpy().view(np.uint64)
+            qh = host_q[(args.steps - 1) % 2]
+            lin = e.search_radius(qh[:32], radius, mode=vc.MODE_LINEAR)
+            for i in range(32):
+                ok = ok and np.array_equal(res[int(off[i]):int(off[i + 1])], lin[i])
+            if not ok:
+                sys.stderr.write("[bench] c2 m=%d: MIH result differs from the linear scan\n" % m)
+        lines[m] = {
+            "value": Q * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "roofline": _mih_roofline(tm, bits),
+            "index_build_s": t_build, "mean_neighbours": float(d_off[Q].item()) / Q, "results_check": "ok" if ok else "FAILED",
+        }
+        e.close()
+    ok = all(v["results_check"] == "ok" for v in lines.values())
+    line = {
+        "metric": "queries/sec (all neighbours within Hamming distance 8, MIH) on 64-bit codes, 100M DB; bit-exact vs linear scan",
+        "value": lines[2]["value"], "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": lines[2]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: %d-bit codes, %.3g-code DB, MIH r=8 neighbour search, m=2 x 32-bit substrings "
+                        "(value); m=4 x 16-bit as variant" % (bits, n),
+            "n_codes": n, "bits": bits, "radius": radius, "queries_per_step": Q, "seed": args.seed,
+            "query_kind": "DB item with 0-8 random bit flips (query-by-image-id use, image_search_client.h:23-25)",
+            "api": "vc_search_radius_dev: queries, results and offsets resident in HBM",
+            "index_build_s": lines[2]["index_build_s"], "mean_neighbours_per_query": lines[2]["mean_neighbours"],
+            "variants": {"m4_s16": {"value": lines[4]["value"], "ms_per_step": lines[4]["ms_per_step"],
+                                    "roofline": lines[4]["roofline"], "results_check": lines[4]["results_check"]}},
+        },
+        "roofline": lines[2]["roofline"],
+        "results_check": "ok" if ok else "FAILED",
+    }
+    if args.cpu_seconds > 0:
+        line["cpu_baseline"] = cpu_baseline_mih(args, 2, "radius", radius=radius)
+    emit(line)
+    return ok
+
+
+def run_knn_mih(args, env, emit):
+    """exact top-k through MIH (SearchWorker::find, search_worker.cc:65-89,159-218) on clustered codes"""
+    torch = env.torch
+    from verticut_amd import engine as vc
+    n, bits, Q, k, m = int(args.n), args.bits, args.queries, args.k, 4
+    rng = np.random.default_rng(args.seed + 3)
+    e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
+    e.add_synthetic(n, seed=args.seed, kind=vc.SYNTH_CLUSTERED, n_centres=max(n // 1000, 1), max_flips=11)
+    e.build_index()
+    host_q = [_near_queries(e, n, Q, bits, 4, rng) for _ in range(2)]
+    dev_q = [torch.from_numpy(h).to(env.device) for h in host_q]
+    d_out = torch.empty((Q, k), dtype=torch.int64, device=env.device)
+    d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run_steps(count):
+        for i in range(count):
+            e.search_knn_dev(dev_q[i % 2].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), mode=vc.MODE_MIH_EXACT, stream=s)
+
+    run_steps(max(args.warmup, 2))
+    env.sync()
+    e.timing()
+    _, elapsed = timed_steps(env, run_steps, args.steps)
+    tm = e.timing()
+    ok = True
+    if not args.no_check:   # exact MIH == full scan on the distances (ids may differ among ties at the k-th distance)
+        got = d_out.cpu().numpy().view(np.uint64)
+        lin, _ = e.search_knn(host_q[(args.steps - 1) % 2][:16], k, mode=vc.MODE_LINEAR)
+        ok = bool(np.array_equal(got[:16] >> np.uint64(32), lin >> np.uint64(32)))
+    e.close()
+    line = {
+        "metric": "queries/sec (exact k-NN top-%d through MIH) on %d-bit clustered codes, %.3g DB; distances bit-exact vs linear scan" % (k, bits, n),
+        "value": Q * args.steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "SearchWorker::find exact MIH: %d-bit codes, %.3g clustered codes (n/1000 centres, <= 11 flips), m=4 x 32-bit, top-%d" % (bits, n, k),
+            "n_codes": n, "bits": bits, "k": k, "queries_per_step": Q, "seed": args.seed,
+            "query_kind": "DB item with 0-4 random bit flips", "api": "vc_search_knn_dev: queries and results resident in HBM",
+        },
+        "roofline": _mih_roofline(tm, bits),
+        "results_check": "ok" if ok else "FAILED",
+    }
+    if args.cpu_seconds > 0:
+        line["cpu_baseline"] = cpu_baseline_mih(args, m, "knn", clustered=True)
+    emit(line)
+    return ok
+
+
+def run_c5shard(args, env, emit):
+    """one GPU's share of BASELINE configs[4]: 256-bit codes, 5e8 of the 4e9 codes, 4096 queries per pass (LDS query tile)"""
+    torch = env.torch
+    from verticut_amd import engine as vc
+    n, bits, Q, k = int(args.n), args.bits, args.queries, args.k
+    rng = np.random.default_rng(args.seed + 5)
+    e = vc.Engine(bits, capacity=n, query_tile=Q, flags=vc.FLAG_LEAN_TIMING)
+    e.add_synthetic(n, seed=args.seed)
+    host_q = [rng.integers(0, 256, size=(Q, bits // 8), dtype=np.uint8) for _ in range(2)]
+    dev_q = [torch.from_numpy(h).to(env.device) for h in host_q]
+    d_out = torch.empty((Q, k), dtype=torch.int64, device=env.device)
+    d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run_steps(count):
+        for i in range(count):
+            e.search_knn_dev(dev_q[i % 2].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), stream=s)
+
+    run_steps(max(1, min(args.warmup, 2)))
+    env.sync()
+    e.timing()
+    _, elapsed = timed_steps(env, run_steps, args.steps)
+    tm = e.timing()
+    ok = True
+    if not args.no_check:
+        res = d_out.cpu().numpy().view(np.uint64)
+        qh = host_q[(args.steps - 1) % 2]
+        ok = bool(np.all(d_cnt.cpu().numpy() == k)) and bool(np.all(res[:, 1:] > res[:, :-1]))
+        for qi in (0, Q // 2, Q - 1):
+            for j in (0, k - 1):
+                code = e.get_code(int(res[qi, j] & np.uint64(0xFFFFFFFF)))
+                ok = ok and int(np.unpackbits(np.bitwise_xor(code, qh[qi])).sum()) == int(res[qi, j] >> np.uint64(32))
+        ok = ok and e.device_status() == 0
+    e.close()
+    launches = max(tm.scan_launches, 1)
+    avg_ms = tm.scan_ms / launches
+    ops = Q * n * (bits // 32) * 2            # SURVEY.md 8(d): Q x N x (B/32 xor + B/32 popcount)
+    achieved = ops / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    line = {
+        "metric": "queries/sec (k-NN top-%d) on %d-bit codes, %.3g-code shard, %d queries per pass; bit-exact vs linear_search" % (k, bits, n, Q),
+        "value": Q * args.steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "one GPU's share of BASELINE configs[4]: %d-bit codes, %.3g of the 4e9 codes, %d queries batched in one "
+                        "LDS query tile, top-%d, linear verify kernel" % (bits, n, Q, k),
+            "n_codes": n, "bits": bits, "k": k, "queries_per_step": Q, "query_tile": Q, "query_kind": "uniform random", "seed": args.seed,
+        },
+        "roofline": {
+            "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_GOPS, "unit": "Gop/s", "frac": achieved / VALU_PEAK_GOPS,
+            "traffic": None, "kernel": "vc_scan_kernel", "launches": tm.scan_launches, "avg_launch_ms": avg_ms,
+            "algorithmic_ops_per_launch": ops,
+            "hbm": {"achieved": tm.scan_bytes / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s"},
+            "note": "4096 queries per database pass put the verify kernel two orders of magnitude on the VALU side of the "
+                    "roofline (SURVEY.md 7.2): the bound is the xor + popcount issue rate, not HBM; no MFMA by design",
+        },
+        "results_check": "ok" if ok else "FAILED",
+    }
+    if args.cpu_seconds > 0:
+        line["cpu_baseline"] = cpu_baseline_linear(args, n)
+    emit(line)
+    return ok
+
+
+def main(argv=None, backend_factory=None, device_kind="cuda", dist_backend=None, out=None):
+    """backend_factory / device_kind / dist_backend / out exist for the CPU rehearsal of the multi-rank flow
+    (tests/test_bench_cpu.py: world size 2 over gloo with a test double for the GPU backend)."""
+    args = parse(argv)
+    if out is None:
+        # The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL writes a five-line version
+        # banner when its communicator comes up), so fd 1 is pointed at stderr for the whole run and the JSON line goes
+        # to a private duplicate of the original stdout.
+        sys.stdout.flush()
+        out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+    def emit(line):
+        out.write(json.dumps(line) + "\n")
+        out.flush()
+
+    env = Env(args, device_kind=device_kind, dist_backend=dist_backend)
+    if args.workload != "c3" and env.world > 1:
+        raise SystemExit("--workload %s is a single-GPU line" % args.workload)
+    try:
+        if args.workload == "c3":
+            ok = run_headline(args, env, emit, backend_factory=backend_factory)
+        elif args.workload == "c2":
+            ok = run_c2(args, env, emit)
+        elif args.workload == "knn_mih":
+            ok = run_knn_mih(args, env, emit)
+        else:
+            ok = run_c5shard(args, env, emit)
+    finally:
+        env.close()
     return 0 if ok else 1
 
 

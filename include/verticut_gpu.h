@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VC_ABI_VERSION 1
+#define VC_ABI_VERSION 2
 
 /* ---- status codes (BaseProxy uses 0 = found/done, 1 = not found/fail: base_proxy.h:10-13) */
 #define VC_OK 0
@@ -109,6 +109,13 @@ typedef struct vc_timing {
   uint32_t scan_launches;
   uint32_t calls;
   uint64_t scan_bytes;     /* algorithmic bytes those launches read: launches * N * B/8 */
+  /* ABI 2 -- the MIH query kernel (mih_query_kernel: probe + verify + merge of the shells of a batch in one launch) */
+  float mih_ms;            /* sum over its launches */
+  uint32_t mih_launches;
+  uint64_t mih_queries;    /* queries those launches served */
+  uint64_t mih_probes;     /* bucket probes = keys enumerated (search_worker.cc:230-264 leaves), all tables */
+  uint64_t mih_hits;       /* non-empty buckets looked up (PROXY_FOUND gets, search_worker.cc:246) */
+  uint64_t mih_entries;    /* bucket entries verified (search_worker.cc:249-257) */
 } vc_timing;
 
 /* ---- lifetime ----------------------------------------------------------------------------

@@ -322,8 +322,11 @@ struct vco_find_stats {
 //   approx (:93-157):  heap cap k*20 (search_worker.h:14), stop iff heap full; emit only the last
 //                      k pops (:142-155)
 // Output: reference order = farthest first, packed dist<<32|id.
-uint32_t vco_mih_find(void* h, const uint8_t* query, uint32_t k, int approximate, int use_bitmap,
-                      uint32_t stop_mult, uint64_t* out, vco_find_stats* st) {
+// threads > 1: the m ranks of one radius iteration run on `threads` std::threads (rank t on thread t % threads), as the
+// reference's `mpirun -n m` runs them on m cores (run_distributed_search.py:12,74); their vectors are concatenated in
+// rank order exactly as gather_vectors does, so the result does not depend on `threads`.
+uint32_t vco_mih_find_mt(void* h, const uint8_t* query, uint32_t k, int approximate, int use_bitmap,
+                         uint32_t stop_mult, uint32_t threads, uint64_t* out, vco_find_stats* st) {
   MihOracle* o = static_cast<MihOracle*>(h);
   const uint32_t s_bits = o->nlb * 8;
   std::priority_queue<ResultSt> qmax;
@@ -336,17 +339,29 @@ uint32_t vco_mih_find(void* h, const uint8_t* query, uint32_t k, int approximate
     search_index[t] = binary_to_int((const char*)query + t * o->nlb, (int)o->nlb);  // :165-167 (unmasked, as in the reference)
   std::vector<uint64_t> sub(o->m, 0), loc(o->m, 0);
   uint64_t n_cand = 0;
+  if (threads < 1) threads = 1;
+  if (threads > o->m) threads = o->m;
 
   while (!is_stop && radius <= s_bits) {            // :170 / :104
-    std::vector<uint64_t> gathered;
-    for (uint32_t t = 0; t < o->m; ++t) {           // ranks in gather order
-      FindCtx c{o, query, use_bitmap != 0, t, 0, 0, &gathered};
+    std::vector<std::vector<uint64_t> > per_rank(o->m);
+    auto rank_work = [&](uint32_t t) {              // search_R_neighbors of rank t (:222-227)
+      FindCtx c{o, query, use_bitmap != 0, t, 0, 0, &per_rank[t]};
       uint32_t start = search_index[t];
       if (o->key_mode == 1 && o->nlb < 4) start &= (1u << s_bits) - 1u;
       enumerate_entry(c, start, 0, (int)radius);
       sub[t] += c.n_sub_reads;
       loc[t] += c.n_local_reads;
+    };
+    if (threads == 1) {
+      for (uint32_t t = 0; t < o->m; ++t) rank_work(t);
+    } else {
+      std::vector<std::thread> th;
+      for (uint32_t w = 0; w < threads; ++w)
+        th.emplace_back([&, w]() { for (uint32_t t = w; t < o->m; t += threads) rank_work(t); });
+      for (auto& x : th) x.join();
     }
+    std::vector<uint64_t> gathered;                 // mpi_coordinator.cc:34-69: concatenation in rank order
+    for (uint32_t t = 0; t < o->m; ++t) gathered.insert(gathered.end(), per_rank[t].begin(), per_rank[t].end());
     n_cand += gathered.size();
     for (size_t i = 0; i < gathered.size(); ++i) {  // :179-199 / :113-132
       uint32_t id = (uint32_t)(gathered[i] & 0xffffffffu);
@@ -400,6 +415,60 @@ uint32_t vco_mih_find(void* h, const uint8_t* query, uint32_t k, int approximate
     st->n_distinct = knn_found.size();
   }
   return cnt;
+}
+
+uint32_t vco_mih_find(void* h, const uint8_t* query, uint32_t k, int approximate, int use_bitmap,
+                      uint32_t stop_mult, uint64_t* out, vco_find_stats* st) {
+  return vco_mih_find_mt(h, query, k, approximate, use_bitmap, stop_mult, 1, out, st);
+}
+
+// Fixed-radius neighbour search (BASELINE configs[1]): every rank runs search_R_neighbors (search_worker.cc:222-227)
+// for the shells 0 .. radius / m of its table -- by the pigeonhole argument an item within full distance `radius`
+// has some substring within radius / m -- the vectors are gathered in rank order (mpi_coordinator.cc:34-69) and the
+// master keeps every distinct id (knn_found_, search_worker.cc:183-190) whose distance is <= radius.  Ascending packed
+// output; returns the number of neighbours (only the first `cap` are written).  `threads` as in vco_mih_find_mt.
+uint64_t vco_mih_radius(void* h, const uint8_t* query, uint32_t radius, uint32_t threads, uint64_t* out, uint64_t cap,
+                        uint64_t* n_probes) {
+  MihOracle* o = static_cast<MihOracle*>(h);
+  const uint32_t s_bits = o->nlb * 8;
+  const uint32_t rsub = std::min(s_bits, radius / o->m);
+  if (threads < 1) threads = 1;
+  if (threads > o->m) threads = o->m;
+  std::vector<std::vector<uint64_t> > per_rank(o->m);
+  std::vector<uint64_t> sub(o->m, 0);
+  auto rank_work = [&](uint32_t t) {
+    uint32_t start = binary_to_int((const char*)query + t * o->nlb, (int)o->nlb);
+    if (o->key_mode == 1 && o->nlb < 4) start &= (1u << s_bits) - 1u;
+    for (uint32_t r = 0; r <= rsub; ++r) {
+      FindCtx c{o, query, false, t, 0, 0, &per_rank[t]};
+      enumerate_entry(c, start, 0, (int)r);
+      sub[t] += c.n_sub_reads;
+    }
+  };
+  if (threads == 1) {
+    for (uint32_t t = 0; t < o->m; ++t) rank_work(t);
+  } else {
+    std::vector<std::thread> th;
+    for (uint32_t w = 0; w < threads; ++w)
+      th.emplace_back([&, w]() { for (uint32_t t = w; t < o->m; t += threads) rank_work(t); });
+    for (auto& x : th) x.join();
+  }
+  std::map<int, bool> knn_found;
+  std::vector<uint64_t> res;
+  for (uint32_t t = 0; t < o->m; ++t)
+    for (uint64_t v : per_rank[t]) {
+      const uint32_t id = (uint32_t)(v & 0xffffffffu);
+      if (knn_found.find((int)id) != knn_found.end()) continue;
+      knn_found[(int)id] = 1;
+      if ((uint32_t)(v >> 32) <= radius) res.push_back(v);
+    }
+  std::sort(res.begin(), res.end());
+  for (uint64_t i = 0; i < res.size() && i < cap; ++i) out[i] = res[i];
+  if (n_probes) {
+    *n_probes = 0;
+    for (uint32_t t = 0; t < o->m; ++t) *n_probes += sub[t];
+  }
+  return res.size();
 }
 
 }  // extern "C"

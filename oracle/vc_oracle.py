@@ -71,6 +71,11 @@ def lib():
         L.vco_mih_find.restype = C.c_uint32
         L.vco_mih_find.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_int, C.c_int, C.c_uint32, u8p,
                                    C.POINTER(FindStats)]
+        L.vco_mih_find_mt.restype = C.c_uint32
+        L.vco_mih_find_mt.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, u8p,
+                                      C.POINTER(FindStats)]
+        L.vco_mih_radius.restype = C.c_uint64
+        L.vco_mih_radius.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_uint32, u8p, C.c_uint64, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -175,13 +180,25 @@ class MihOracle:
         n = lib().vco_mih_bucket(self.h, table, index, _p(ids), cap)
         return ids[: min(n, cap)].copy()
 
-    def find(self, query, k, approximate=False, use_bitmap=False, stop_mult=4):
-        """Returns (packed farthest-first, FindStats)."""
+    def find(self, query, k, approximate=False, use_bitmap=False, stop_mult=4, threads=1):
+        """Returns (packed farthest-first, FindStats).  threads = ranks run concurrently (mpirun -n m); same result."""
         query = _bytes(query)
         out = np.empty(max(k, 1) * (1 if not approximate else 1) + 8, dtype=np.uint64)
         st = FindStats()
-        c = lib().vco_mih_find(self.h, _p(query), k, int(approximate), int(use_bitmap), stop_mult, _p(out), C.byref(st))
+        c = lib().vco_mih_find_mt(self.h, _p(query), k, int(approximate), int(use_bitmap), stop_mult, threads, _p(out),
+                                  C.byref(st))
         return out[:c].copy(), st
+
+    def radius(self, query, radius, threads=1, cap=1 << 16):
+        """all items within full distance <= radius (search_R_neighbors shells 0..radius/m per rank, gather, dedup):
+        (packed ascending, number of bucket gets issued over all ranks)"""
+        query = _bytes(query)
+        out = np.empty(cap, dtype=np.uint64)
+        probes = C.c_uint64()
+        c = lib().vco_mih_radius(self.h, _p(query), radius, threads, _p(out), cap, C.byref(probes))
+        if c > cap:
+            return self.radius(query, radius, threads, cap=int(c))
+        return out[:c].copy(), probes.value
 
 
 # ------------------------------------------------------------------ numpy helpers (contract checks)

@@ -423,10 +423,15 @@ static void timing_end(vc_engine* e) {
 int vc_get_timing(const vc_engine* ce, vc_timing* t) {
   vc_engine* e = const_cast<vc_engine*>(ce);
   if (!e || !t) return VC_ERR_INVALID;
-  if (!e->ev_calls.empty() || !e->ev_scans.empty()) {
+  if (!e->ev_calls.empty() || !e->ev_scans.empty() || e->mih) {
     int rc = bind_device(e);
     if (rc) return rc;
     vc_timing lt{};
+    if (e->mih) {
+      uint64_t tot[4];
+      vc_mih_timing(e->mih, &lt.mih_ms, &lt.mih_launches, tot, e->stream);
+      lt.mih_probes = tot[0]; lt.mih_hits = tot[1]; lt.mih_entries = tot[2]; lt.mih_queries = tot[3];
+    }
     for (auto& pr : e->ev_calls) {
       float ms = 0;
       VC_HIP(e, hipEventSynchronize(pr.second));

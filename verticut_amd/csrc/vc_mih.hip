@@ -137,6 +137,7 @@ struct MihState {          // all arrays indexed by the query's slot in the tile
   uint32_t* radius;        // last shell searched
   uint64_t* topk;          // [slot][k] select output
   uint32_t* topn;          // [slot]
+  unsigned long long* work;   // [slot][4] mih_query_kernel: bucket probes, non-empty buckets, bucket entries verified, -
 };
 
 struct ProbeParams {
@@ -578,7 +579,15 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
   bool spilled = false;            // radius mode: results went to the global ring unsorted (block-uniform)
   uint32_t ring_fill = 0;          // radius mode: entries already in the global ring       (block-uniform)
   unsigned long long sub = 0, loc = 0;   // get_stat counters of table 0 (block-uniform)
+  unsigned long long w_probes = 0, w_hits = 0, w_entries = 0;   // algorithmic work of this query (block-uniform)
   uint64_t* const ring = p.st.ring + (uint64_t)slot * p.cap;
+  auto put_work = [&]() {
+    if (tid == 0) {
+      p.st.work[slot * 4 + 0] = w_probes;
+      p.st.work[slot * 4 + 1] = w_hits;
+      p.st.work[slot * 4 + 2] = w_entries;
+    }
+  };
 
   // ---- sort s_buf[0 .. kk + ncand) and keep the k smallest: new top-k, new threshold
   auto merge = [&]() {
@@ -649,6 +658,8 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
     }
     if (tid == 0) s_pref[H] = total;
     __syncthreads();
+    w_hits += H;
+    w_entries += total;
 
     uint32_t seen_acc = 0;
     for (uint32_t e0 = 0; e0 < total; e0 += MQ_ROUND) {
@@ -890,6 +901,8 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
     }
     if (s_nh) drain();
     __syncthreads();
+    for (uint32_t r = 0; r <= p.r_last; ++r) w_probes += (unsigned long long)m * c_binom[s][r];
+    put_work();
     if (!spilled) {
       merge();                                       // sorts the LDS results (kk = their number)
       for (uint32_t i = tid; i < kk; i += MQ_BLK)
@@ -921,6 +934,7 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
     // get_stat counters of table 0 (rank 0's, search_worker.cc:24-30): every leaf is a bitmap test when the bitmap
     // is attached (:239) and a get only where the bit is set (:245); without it every leaf is a get
     const unsigned long long leaves = c_binom[s][r];
+    w_probes += leaves * m;
     if (p.flags & VC_FLAG_USE_BITMAP) {
       loc += leaves;
       sub += s_hits0;
@@ -936,6 +950,7 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
     else                            // search_worker.cc:201-205: size == k && top.dist <= radius * 4 (radius already incremented)
       stop = kk == p.k && (uint32_t)(kth >> 32) <= (r + 1) * p.stop_mult;
     if (stop || r == S) {
+      put_work();
       for (uint32_t i = tid; i < p.k; i += MQ_BLK) p.out[(uint64_t)slot * p.k + i] = i < kk ? s_buf[i] : VC_PACK_INF;
       if (tid == 0) {
         p.out_cnt[slot] = kk;
@@ -949,6 +964,7 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
     __syncthreads();
   }
   // not finished: hand the query to the multi-block shells (state exactly as mih_commit_kernel leaves it)
+  put_work();
   for (uint32_t i = tid; i < kk; i += MQ_BLK) ring[i] = s_buf[i];
   if (tid == 0) {
     p.st.count[slot] = kk;
@@ -963,6 +979,26 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
   }
 }
 
+
+// sum the per-query work counters of one mih_query_kernel launch into the index-wide totals (vc_get_timing)
+__global__ void __launch_bounds__(256) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
+                                                              unsigned long long* __restrict__ totals) {
+  __shared__ unsigned long long s_t[3];
+  if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long a = 0, b = 0, c = 0;
+  for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
+    a += work[i * 4 + 0];
+    b += work[i * 4 + 1];
+    c += work[i * 4 + 2];
+  }
+  atomicAdd(&s_t[0], a);
+  atomicAdd(&s_t[1], b);
+  atomicAdd(&s_t[2], c);
+  __syncthreads();
+  if (threadIdx.x < 3) totals[threadIdx.x] += s_t[threadIdx.x];
+  if (threadIdx.x == 3) totals[3] += nq;
+}
 
 // per-query result segments of the radius search: ring[q][0 .. min(count, cap)) sorted ascending in place.
 // One 1024-thread block per query; segments the query kernel already sorted (flag) or empty ones are skipped.
@@ -1046,6 +1082,10 @@ struct VcMihIndex {
   size_t tile_bytes = 0;
   uint32_t* d_lists = nullptr;   // 3 * MIH_QTILE + 4 counters
   uint32_t* h_ctr = nullptr;     // pinned: the two counters the host reads back after every shell
+  // measurement (vc_get_timing): event pairs around every mih_query_kernel launch, device totals of its work counters
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  unsigned long long* d_totals = nullptr;   // probes | non-empty buckets | entries verified | queries
 };
 
 #define MIH_CHECK(call)                                                                                  \
@@ -1080,6 +1120,8 @@ void vc_mih_free(VcMihIndex* ix) {
   (void)hipFree(ix->d_tile);
   (void)hipFree(ix->d_lists);
   if (ix->h_ctr) (void)hipHostFree(ix->h_ctr);
+  for (auto& pr : ix->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  (void)hipFree(ix->d_totals);
   delete ix;
 }
 
@@ -1297,7 +1339,7 @@ static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, MihState* st, s
   auto take = [&](size_t b) { size_t o = bytes; bytes += (b + 255) & ~(size_t)255; return o; };
   const size_t o_thresh = take(Q * 8), o_ring = take(Q * cap * 8), o_count = take(Q * 4), o_prev = take(Q * 4),
                o_seen = take(Q * 8), o_sub = take(Q * 8), o_loc = take(Q * 8), o_radius = take(Q * 4),
-               o_topk = take(Q * (size_t)k * 8), o_topn = take(Q * 4);
+               o_topk = take(Q * (size_t)k * 8), o_topn = take(Q * 4), o_work = take(Q * 4 * 8);
   if (bytes > ix->tile_bytes) {
     if (ix->d_tile) MIH_CHECK(hipFree(ix->d_tile));
     ix->d_tile = nullptr;
@@ -1317,6 +1359,7 @@ static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, MihState* st, s
   st->radius = (uint32_t*)(b + o_radius);
   st->topk = (uint64_t*)(b + o_topk);
   st->topn = (uint32_t*)(b + o_topn);
+  st->work = (unsigned long long*)(b + o_work);
   return VC_OK;
 }
 
@@ -1346,6 +1389,52 @@ static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, ui
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+// launch + measurement: events on the launch stream around the kernel, then the reduction of its work counters
+static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s) {
+  if (!ix->d_totals) {
+    hipError_t r = hipMalloc((void**)&ix->d_totals, 32);
+    if (r == hipSuccess) r = hipMemsetAsync(ix->d_totals, 0, 32, s);
+    if (r != hipSuccess) return r;
+  }
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (ix->ev_used < 4096) {
+    if (ix->ev_used == ix->ev_pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) == hipSuccess) {
+        if (hipEventCreate(&b) == hipSuccess) ix->ev_pool.emplace_back(a, b); else (void)hipEventDestroy(a);
+      }
+    }
+    if (ix->ev_used < ix->ev_pool.size()) ev = &ix->ev_pool[ix->ev_used++];
+  }
+  if (ev) (void)hipEventRecord(ev->first, s);
+  hipError_t r = launch_query_kernel(p, W, nq, s);
+  if (ev) (void)hipEventRecord(ev->second, s);
+  if (r != hipSuccess) return r;
+  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(256), 0, s, p.st.work, nq, ix->d_totals);
+  return hipGetLastError();
+}
+
+void vc_mih_timing(VcMihIndex* ix, float* ms, uint32_t* launches, uint64_t totals[4], hipStream_t s) {
+  *ms = 0;
+  *launches = 0;
+  totals[0] = totals[1] = totals[2] = totals[3] = 0;
+  if (!ix) return;
+  for (size_t i = 0; i < ix->ev_used; ++i) {
+    float t = 0;
+    if (hipEventSynchronize(ix->ev_pool[i].second) == hipSuccess && hipEventElapsedTime(&t, ix->ev_pool[i].first, ix->ev_pool[i].second) == hipSuccess) {
+      *ms += t;
+      ++*launches;
+    }
+  }
+  ix->ev_used = 0;
+  if (ix->d_totals) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(h, ix->d_totals, 32, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemsetAsync(ix->d_totals, 0, 32, s) == hipSuccess &&
+        hipStreamSynchronize(s) == hipSuccess)
+      for (int i = 0; i < 4; ++i) totals[i] = h[i];
+  }
 }
 
 static uint32_t binom_host(uint32_t n, uint32_t k) {
@@ -1412,7 +1501,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0;
       const auto t_q = std::chrono::steady_clock::now();
       MIH_CHECK(hipMemsetAsync(d_ctr, 0, 16, s));
-      MIH_CHECK(launch_query_kernel(qp, ix->W, qt, s));
+      MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
       MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 4, hipMemcpyDeviceToHost, s));
       MIH_CHECK(hipStreamSynchronize(s));
       n_heavy = n_cur = h_ctr[2];
@@ -1572,7 +1661,7 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
           qp.cols = d_cols; qp.stride = stride; qp.n = ix->n; qp.tables = ix->d_tables; qp.queries = d_q + (size_t)q0 * W;
           qp.st = st; qp.m = ix->m; qp.sbits = ix->sbits; qp.id_base = id_base; qp.flags = ix->flags; qp.cap = cap; qp.k = 0;
           qp.mode = MQ_MODE_RADIUS; qp.radius = radius; qp.r_last = rsub; qp.buf_entries = 2048;
-          R_CHECK(launch_query_kernel(qp, W, qt, s));
+          R_CHECK(timed_query_launch(ix, qp, W, qt, s));
           sorted_flag = d_sorted;
         } else {
           uint32_t* list = ix->d_lists;

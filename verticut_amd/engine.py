@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VERTICUT_GPU_LIB") or os.path.join(_HERE, "lib", "libverticut_gpu.so")   # env: A/B builds
 
-VC_ABI_VERSION = 1
+VC_ABI_VERSION = 2
 VC_OK, VC_NOT_FOUND = 0, 1
 VC_ERR_INVALID, VC_ERR_NO_DEVICE, VC_ERR_HIP, VC_ERR_NOMEM, VC_ERR_STATE, VC_ERR_CAPACITY = -1, -2, -3, -4, -5, -6
 MODE_LINEAR, MODE_MIH_EXACT, MODE_MIH_APPROX = 0, 1, 2
@@ -50,6 +50,8 @@ class VcTiming(C.Structure):
     _fields_ = [
         ("total_ms", C.c_float), ("scan_ms", C.c_float), ("scan_launches", C.c_uint32), ("calls", C.c_uint32),
         ("scan_bytes", C.c_uint64),
+        ("mih_ms", C.c_float), ("mih_launches", C.c_uint32), ("mih_queries", C.c_uint64), ("mih_probes", C.c_uint64),
+        ("mih_hits", C.c_uint64), ("mih_entries", C.c_uint64),
     ]
 
 

@@ -49,6 +49,10 @@ class GpuBackend:
     def timing(self):
         return self.engine.timing()
 
+    def get_code(self, gid):
+        """ID -> BinaryCode of this shard (None when the id lives elsewhere)"""
+        return self.engine.get_code(gid)
+
     def unrecovered(self):
         """calls whose device-side ring-overflow recovery gave up since the last query (vc_device_status); 0 normally"""
         return self.engine.device_status()
