@@ -139,11 +139,19 @@ int vc_size(const vc_engine* e, uint64_t* n);
  *   bitmap file raw 2^substr_bits-bit LSB-first uint32 words of one table (generate_bitmap.cc:99-125,
  *               read back by bitmap_deamon.cc:41-65)
  * vc_load_code_file appends up to max_records records (0 = all) and reports how many were read;
- * vc_save_code_file writes the resident records back in id order; vc_write_bitmap_file needs vc_build_index.
- * The CSR tables themselves are not persisted: rebuilding them from the records takes ~0.5 s per 1e9 codes. */
+ * vc_save_code_file writes the resident records back in id order; vc_write_bitmap_file needs vc_build_index. */
 int vc_load_code_file(vc_engine* e, const char* path, uint64_t max_records, uint64_t* n_read);
 int vc_save_code_file(vc_engine* e, const char* path);
 int vc_write_bitmap_file(vc_engine* e, uint32_t table, const char* path);
+/* Reads a bitmap file of that format (what bitmap_deamon.cc:41-65 loads) and checks it word for word against the
+ * bitmap of the resident index: VC_OK = identical (the file belongs to this database), VC_ERR_STATE = it differs
+ * (*n_mismatch_words, may be NULL, says in how many 32-bit words), VC_ERR_INVALID = wrong size / unreadable. */
+int vc_read_bitmap_file(vc_engine* e, uint32_t table, const char* path, uint64_t* n_mismatch_words);
+/* Index persistence (the step build_hash_tables.cc performs against the KV tier, kept on disk instead): the sorted id
+ * runs, bucket offsets, occupancy bitmaps and rank directories of every table.  vc_load_index needs the same records
+ * resident (vc_load_code_file / vc_add_codes) and refuses a file built for another shape (VC_ERR_STATE). */
+int vc_save_index(vc_engine* e, const char* path);
+int vc_load_index(vc_engine* e, const char* path);
 /* ID -> BinaryCode get (linear_search.cc:45-46; by-id query path image_search_client.h:23-25).
  * id is a global id; out = bits/8 bytes.  VC_NOT_FOUND if id is not in this shard. */
 int vc_get_code(vc_engine* e, uint32_t id, void* out);

@@ -168,3 +168,106 @@ def test_gpu_proxy_behaves_like_a_base_proxy(vc, oracle, tmp_path):
         exp_list += b"\x0a" + varint(len(pair)) + pair
     assert ("kv_bucket rc=0 " + exp_list.hex()) in out
     assert ("kv_id7 rc=0 " + (b"\x0a" + varint(16) + codes[7].tobytes()).hex()) in out
+
+
+@pytest.mark.parametrize("bits,m", [(64, 4), (64, 2)])
+def test_driver_reference_quirks_mode(vc, oracle, tmp_path, bits, m):
+    """VC_REF_QUIRKS=1: the drivers reproduce the reference where it is NOT exact -- 16-bit substrings with binaryToInt's
+    sign-extended keys (Pilaf/image_tools.h:13) and two tables with the stop rule's literal 4 (search_worker.cc:204):
+    distances, radius and n_sub_reads equal MihOracle(key_mode=0) / stop_mult=4; the default mode equals the exact
+    variant of the oracle instead."""
+    n, k = 30000, 10
+    rng = np.random.default_rng(5 + m)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=150, max_flips=6)
+    q = codes[rng.integers(0, n, size=9)].copy()
+    q[:, 1] ^= 0x90                       # flips the top bit of a 16-bit substring: where the sign extension bites
+    (tmp_path / "lsh.code").write_bytes(codes.tobytes())
+    (tmp_path / "query.code").write_bytes(q.tobytes())
+    for quirks, key_mode, stop_mult in (("1", 0, 4), ("0", 1, min(m, 4))):
+        out = _run([tmp_path / "lsh.code", n, bits, bits // m, k, "pilaf", 0, 0, -1, tmp_path / "query.code"],
+                   {"VC_PRINT_RESULTS": "1", "VC_REF_QUIRKS": quirks})
+        blocks = re.split(r"^query \d+\n", out, flags=re.M)[1:]
+        mo = oracle.MihOracle(codes, m, key_mode=key_mode)
+        for i, blk in enumerate(blocks):
+            pairs = [(int(a), int(b)) for a, b in re.findall(r"^(\d+) : (\d+)$", blk, flags=re.M)]
+            st = re.search(r"n_sub_reads : (\d+), n_local_reads : (\d+), radius : (\d+)", blk)
+            ores, ost = mo.find(q[i], k, stop_mult=stop_mult)
+            assert [d for _, d in pairs] == [int(x >> SH) for x in ores], (quirks, i)
+            assert (int(st.group(1)), int(st.group(3))) == (ost.n_sub_reads, ost.radius), (quirks, i)
+            for a, d in pairs:
+                assert oracle.hamming(codes[a], q[i]) == d
+
+
+def test_bitmap_file_read_back_and_verify(vc, oracle, tmp_path):
+    """generate_bitmap.cc:99-125 writes <code file>_bmp_<t>_2b_4k.raw, bitmap_deamon.cc:41-65 reads it back: a file the engine
+    wrote verifies, a HAND-MADE file (bits set one by one through the oracle's ImageBitmap::set_idx restatement, which
+    is pinned to the reference's bitmap.cc) verifies, and a file with one foreign bit, or of the wrong size, does not."""
+    n, bits, m = 25000, 64, 4
+    codes = oracle.gen_codes(n, bits, 11, kind=1, n_centres=60, max_flips=5)
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        e.build_index()
+        for t in range(m):
+            own = tmp_path / ("own_%d.raw" % t)
+            e.write_bitmap_file(t, own)
+            assert e.read_bitmap_file(t, own) == 0
+            hand = np.zeros((1 << 16) // 32, dtype=np.uint32)
+            for c in codes:                                                    # generate_bitmap.cc:111-114: one set_idx per record
+                oracle.lib().vco_bitmap_set(hand.ctypes.data, int.from_bytes(bytes(c[2 * t:2 * t + 2]), "little"))
+            (tmp_path / "hand.raw").write_bytes(hand.tobytes())
+            assert e.read_bitmap_file(t, tmp_path / "hand.raw") == 0
+        free_key = next(k for k in range(1 << 16) if not e.bitmap_test(0, k))
+        bad = np.frombuffer((tmp_path / "own_0.raw").read_bytes(), dtype=np.uint32).copy()
+        oracle.lib().vco_bitmap_set(bad.ctypes.data, free_key)
+        (tmp_path / "bad.raw").write_bytes(bad.tobytes())
+        assert e.read_bitmap_file(0, tmp_path / "bad.raw") == 1                # one word differs
+        assert e.read_bitmap_file(1, tmp_path / "own_0.raw") > 0               # another table's file
+        (tmp_path / "short.raw").write_bytes(bad.tobytes()[:-4])
+        with pytest.raises(vc.VcError) as ei:
+            e.read_bitmap_file(0, tmp_path / "short.raw")
+        assert ei.value.code == vc.VC_ERR_INVALID
+        (tmp_path / "long.raw").write_bytes(bad.tobytes() + b"\0\0\0\0")
+        with pytest.raises(vc.VcError):
+            e.read_bitmap_file(0, tmp_path / "long.raw")
+
+
+@pytest.mark.parametrize("bits,m", [(128, 4), (64, 4)])
+def test_index_save_and_load(vc, oracle, tmp_path, bits, m):
+    """the built index (bucket lists of build_hash_tables.cc:36-64 as id runs + offsets, bitmaps, rank directories)
+    survives a round trip through a file: same buckets, same search results and statistics; a file built for another
+    database shape is refused."""
+    n, k = 30000, 20
+    rng = np.random.default_rng(bits)
+    codes = oracle.gen_codes(n, bits, 3, kind=1, n_centres=120, max_flips=6)
+    q = codes[rng.integers(0, n, size=8)].copy()
+    q[:, 0] ^= 0x06
+    path = tmp_path / "index.vcidx"
+    with vc.Engine(bits, capacity=n, n_tables=m, id_base=7) as e:
+        e.add_codes(codes)
+        e.build_index()
+        ref = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        rad = e.search_radius(q[:3], 7, mode=vc.MODE_MIH_EXACT)
+        e.save_index(path)
+    with vc.Engine(bits, capacity=n, n_tables=m, id_base=7) as e2:
+        e2.add_codes(codes)
+        e2.load_index(path)                                                    # no vc_build_index here
+        got = e2.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        assert [(s.radius, s.n_sub_reads, s.n_candidates) for s in got[2]] == [(s.radius, s.n_sub_reads, s.n_candidates) for s in ref[2]]
+        assert all(np.array_equal(a, b) for a, b in zip(e2.search_radius(q[:3], 7, mode=vc.MODE_MIH_EXACT), rad))
+        mo = oracle.MihOracle(codes, m, key_mode=1, id_base=7)
+        for t in range(m):
+            key = mo.key(codes[123], t)
+            ids, bc, total = e2.get_bucket(t, key)
+            assert np.array_equal(ids, mo.bucket(t, key)) and total == len(ids)
+    with vc.Engine(bits, capacity=n, n_tables=m, id_base=7) as e3:             # fewer records resident than the file indexes
+        e3.add_codes(codes[:-1])
+        with pytest.raises(vc.VcError) as ei:
+            e3.load_index(path)
+        assert ei.value.code == vc.VC_ERR_STATE
+    (tmp_path / "junk").write_bytes(b"not an index" * 10)
+    with vc.Engine(bits, capacity=n, n_tables=m) as e4:
+        e4.add_codes(codes)
+        with pytest.raises(vc.VcError) as ei:
+            e4.load_index(tmp_path / "junk")
+        assert ei.value.code == vc.VC_ERR_INVALID

@@ -242,3 +242,58 @@ def test_bucket_order_code_copies_change_nothing(vc, oracle, monkeypatch):
     mo = oracle.MihOracle(codes, m, key_mode=1)
     ores, ost = mo.find(q[0], k, stop_mult=4)
     _check_contract(b[0][0, : b[1][0]], ores)
+
+
+@pytest.mark.parametrize("bits,m,k", [(128, 4, 100), (64, 4, 50), (64, 2, 20)])
+def test_host_loop_path_equals_the_query_kernel(vc, oracle, monkeypatch, bits, m, k):
+    """VC_MIH_HOST_LOOP=1 runs every shell through the multi-block kernels (one launch sequence per shell, the round-1
+    loop, still the path of the shells beyond the query kernel's budget): same rows, counts, statistics, radius search."""
+    n = 50000
+    rng = np.random.default_rng(bits + m)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=250, max_flips=8)
+    q = _near_queries(codes, 14, rng, 4)
+    got = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VC_MIH_HOST_LOOP", flag)
+        with vc.Engine(bits, capacity=n, n_tables=m) as e:
+            e.add_codes(codes)
+            e.build_index()
+            res, cnt, st = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+            ares, acnt, ast = e.search_knn(q, 5, mode=vc.MODE_MIH_APPROX, with_stats=True)
+            rad = e.search_radius(q[:5], 9, mode=vc.MODE_MIH_EXACT)
+            got[flag] = (res, cnt, [(s.radius, s.n_sub_reads, s.n_candidates) for s in st], ares, acnt,
+                         [(s.radius, s.n_candidates) for s in ast], rad)
+    a, b = got["0"], got["1"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and a[5] == b[5]
+    assert all(np.array_equal(x, y) for x, y in zip(a[6], b[6]))
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    for i in range(3):
+        ores, ost = mo.find(q[i], k, stop_mult=min(m, 4))
+        _check_contract(a[0][i, : a[1][i]], ores)
+        assert a[2][i][:2] == (ost.radius, ost.n_sub_reads)
+
+
+def test_queries_that_outlive_the_query_kernel_continue_in_the_multi_block_shells(vc, oracle):
+    """uniform random 128-bit codes: the k-th neighbour is ~40 bits away, so the radius loop runs to shell 8-10, far
+    beyond the shells the one-block-per-query kernel covers (0..4): state hand-over to the multi-block kernels, mixed
+    with queries that finish in the first shells; radius / n_sub_reads must be the oracle's."""
+    n, bits, m, k = 3000, 128, 4, 3
+    codes = oracle.gen_codes(n, bits, 77)
+    rng = np.random.default_rng(1)
+    q = np.stack([codes[5], rng.integers(0, 256, size=16, dtype=np.uint8), codes[100], rng.integers(0, 256, size=16, dtype=np.uint8)])
+    q[2, 0] ^= 1
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        e.build_index()
+        got, cnt, st = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        lin, _ = e.search_knn(q, k)
+        assert np.array_equal(got >> SH, lin >> SH)
+        for i in (0, 2):                                   # the far queries cost the CPU oracle ~10^8 probes: check the near ones
+            ores, ost = mo.find(q[i], k, stop_mult=4)
+            _check_contract(got[i, : cnt[i]], ores)
+            assert (st[i].radius, st[i].n_sub_reads) == (ost.radius, ost.n_sub_reads)
+        assert max(s.radius for s in st) > 4               # the hand-over really happened
+        for s in st:                                       # n_sub_reads = every leaf of every shell searched (no bitmap attached)
+            assert s.n_sub_reads == sum(__import__("math").comb(32, r) for r in range(s.radius + 1))

@@ -362,6 +362,53 @@ int vc_write_bitmap_file(vc_engine* e, uint32_t table, const char* path) {
   return rc;
 }
 
+// bitmap_deamon.cc:41-65 reads the files generate_bitmap.cc:99-125 wrote back into memory; here the file is checked word
+// for word against the bitmap the index derived from the resident records (the two are equal exactly when the file was
+// generated from the same code file), which is what "attaching" it means for an index whose rank directory depends on it
+int vc_read_bitmap_file(vc_engine* e, uint32_t table, const char* path, uint64_t* n_mismatch_words) {
+  if (!e || !path) return VC_ERR_INVALID;
+  if (n_mismatch_words) *n_mismatch_words = 0;
+  if (!e->mih) return fail(e, VC_ERR_STATE, "no index built");
+  if (table >= e->m) return VC_ERR_INVALID;
+  int rc = bind_device(e);
+  if (rc) return rc;
+  FILE* fh = fopen(path, "rb");
+  if (!fh) return fail(e, VC_ERR_INVALID, "Can't open file %s.", path);   // bitmap_deamon.cc:48-51
+  const uint64_t words = (1ull << e->sbits) / 32;
+  const uint64_t batch = 16ull << 20;
+  std::vector<uint32_t> file_w((size_t)std::min(words, batch)), dev_w((size_t)std::min(words, batch));
+  uint64_t bad = 0;
+  for (uint64_t off = 0; off < words && rc == VC_OK; off += batch) {
+    const uint64_t cnt = std::min(batch, words - off);
+    if (fread(file_w.data(), 4, cnt, fh) != cnt) { rc = fail(e, VC_ERR_INVALID, "%s is shorter than 2^%u bits", path, e->sbits); break; }
+    rc = vc_mih_bitmap_read(e->mih, table, off, cnt, dev_w.data(), e->stream, &e->err);
+    for (uint64_t i = 0; i < cnt && rc == VC_OK; ++i) bad += file_w[i] != dev_w[i];
+  }
+  if (rc == VC_OK && fgetc(fh) != EOF) rc = fail(e, VC_ERR_INVALID, "%s is longer than 2^%u bits", path, e->sbits);
+  fclose(fh);
+  if (n_mismatch_words) *n_mismatch_words = bad;
+  if (rc == VC_OK && bad) rc = fail(e, VC_ERR_STATE, "%s differs from the bitmap of the resident records in %llu words", path, (unsigned long long)bad);
+  return rc;
+}
+
+int vc_save_index(vc_engine* e, const char* path) {
+  if (!e || !path) return VC_ERR_INVALID;
+  if (!e->mih) return fail(e, VC_ERR_STATE, "no index built");
+  int rc = bind_device(e);
+  if (rc) return rc;
+  return vc_mih_save(e->mih, path, e->stream, &e->err);
+}
+
+int vc_load_index(vc_engine* e, const char* path) {
+  if (!e || !path) return VC_ERR_INVALID;
+  if (e->m == 0) return fail(e, VC_ERR_STATE, "engine was created with n_tables = 0 (linear only)");
+  int rc = bind_device(e);
+  if (rc) return rc;
+  if (e->mih) { vc_mih_free(e->mih); e->mih = nullptr; }
+  return vc_mih_load(&e->mih, path, e->d_cols, e->stride, e->n, e->W, e->m, e->sbits, e->cfg.id_base, e->cfg.flags, e->n_cu, e->cap,
+                     e->knobs, e->stream, &e->err);
+}
+
 int vc_get_code(vc_engine* e, uint32_t id, void* out) {
   if (!e || !out) return VC_ERR_INVALID;
   if (id < e->cfg.id_base || (uint64_t)id - e->cfg.id_base >= e->n) return VC_NOT_FOUND;

@@ -1332,6 +1332,156 @@ int vc_mih_bitmap_read(VcMihIndex* ix, uint32_t table, uint64_t word_off, uint64
   return VC_OK;
 }
 
+// ---- index persistence ------------------------------------------------------------------
+// File = header + per table {n_unique, offsets length, ids[n], offsets[], bitmap[2^s/32], blockrank[2^24] (s == 32)}.
+// The bitmap section is byte for byte what generate_bitmap.cc:122-125 writes for that table; the bucket lists
+// (build_hash_tables.cc:36-64) are the contiguous id runs delimited by offsets[].
+struct VcIndexHeader {
+  char magic[8];
+  uint32_t version, bits, m, sbits, id_base, reserved;
+  uint64_t n;
+};
+static const char kIndexMagic[8] = {'V', 'C', 'M', 'I', 'H', 'I', 'D', 'X'};
+
+static int copy_out(FILE* fh, const void* d_src, size_t bytes, hipStream_t s, std::vector<char>& buf, std::string* err) {
+  for (size_t off = 0; off < bytes; off += buf.size()) {
+    const size_t cnt = std::min(buf.size(), bytes - off);
+    MIH_CHECK(hipMemcpyAsync(buf.data(), (const char*)d_src + off, cnt, hipMemcpyDeviceToHost, s));
+    MIH_CHECK(hipStreamSynchronize(s));
+    if (fwrite(buf.data(), 1, cnt, fh) != cnt) {
+      if (err) *err = "short write to the index file";
+      return VC_ERR_INVALID;
+    }
+  }
+  return VC_OK;
+}
+
+static int copy_in(FILE* fh, void* d_dst, size_t bytes, hipStream_t s, std::vector<char>& buf, std::string* err) {
+  for (size_t off = 0; off < bytes; off += buf.size()) {
+    const size_t cnt = std::min(buf.size(), bytes - off);
+    if (fread(buf.data(), 1, cnt, fh) != cnt) {
+      if (err) *err = "index file is truncated";
+      return VC_ERR_INVALID;
+    }
+    MIH_CHECK(hipMemcpyAsync((char*)d_dst + off, buf.data(), cnt, hipMemcpyHostToDevice, s));
+    MIH_CHECK(hipStreamSynchronize(s));
+  }
+  return VC_OK;
+}
+
+int vc_mih_save(VcMihIndex* ix, const char* path, hipStream_t s, std::string* err) {
+  FILE* fh = fopen(path, "wb");
+  if (!fh) {
+    if (err) *err = std::string("Can't create file ") + path + ".";
+    return VC_ERR_INVALID;
+  }
+  VcIndexHeader h{};
+  memcpy(h.magic, kIndexMagic, 8);
+  h.version = 1; h.bits = ix->W * 64; h.m = ix->m; h.sbits = ix->sbits; h.id_base = ix->id_base; h.n = ix->n;
+  int rc = fwrite(&h, sizeof h, 1, fh) == 1 ? VC_OK : VC_ERR_INVALID;
+  std::vector<char> buf(32u << 20);
+  const uint64_t bm_words = std::max<uint64_t>((1ull << ix->sbits) / 32, 8);
+  for (uint32_t t = 0; t < ix->m && rc == VC_OK; ++t) {
+    const VcTableView& tv = ix->h_tables[t];
+    const uint64_t off_len = ix->sbits == 32 ? (uint64_t)tv.n_unique + 1 : (1ull << ix->sbits) + 1;
+    const uint64_t th[2] = {tv.n_unique, off_len};
+    if (fwrite(th, sizeof th, 1, fh) != 1) rc = VC_ERR_INVALID;
+    if (rc == VC_OK) rc = copy_out(fh, tv.ids, (size_t)ix->n * 4, s, buf, err);
+    if (rc == VC_OK) rc = copy_out(fh, tv.offsets, (size_t)off_len * 4, s, buf, err);
+    if (rc == VC_OK) rc = copy_out(fh, tv.bitmap, (size_t)bm_words * 4, s, buf, err);
+    if (rc == VC_OK && ix->sbits == 32) rc = copy_out(fh, tv.blockrank, (size_t)(1u << 24) * 4, s, buf, err);
+  }
+  if (fclose(fh) != 0 && rc == VC_OK) rc = VC_ERR_INVALID;
+  if (rc == VC_ERR_INVALID && err && err->empty()) *err = "short write to the index file";
+  return rc;
+}
+
+int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t m,
+                uint32_t sbits, uint32_t id_base, uint32_t flags, uint32_t n_cu, uint32_t cand_cap, const VcKnobs& knobs,
+                hipStream_t s, std::string* err) {
+  FILE* fh = fopen(path, "rb");
+  if (!fh) {
+    if (err) *err = std::string("Can't open file ") + path + ".";
+    return VC_ERR_INVALID;
+  }
+  VcIndexHeader h{};
+  if (fread(&h, sizeof h, 1, fh) != 1 || memcmp(h.magic, kIndexMagic, 8) != 0 || h.version != 1) {
+    fclose(fh);
+    if (err) *err = "not a verticut_gpu index file (bad magic or version)";
+    return VC_ERR_INVALID;
+  }
+  if (h.bits != W * 64 || h.m != m || h.sbits != sbits || h.n != n || h.id_base != id_base) {
+    fclose(fh);
+    if (err) *err = "index file was built for another database shape (bits / n_tables / records / id_base differ)";
+    return VC_ERR_STATE;
+  }
+  int rc = upload_binom(err);
+  if (rc) { fclose(fh); return rc; }
+  VcMihIndex* ix = new VcMihIndex();
+  ix->W = W; ix->m = m; ix->sbits = sbits; ix->id_base = id_base; ix->flags = flags; ix->n_cu = n_cu; ix->cap = cand_cap; ix->n = n;
+  ix->knobs = knobs;
+  ix->h_tables.resize(m);
+  std::vector<char> buf(32u << 20);
+  const uint64_t bm_words = std::max<uint64_t>((1ull << sbits) / 32, 8);
+  bool want_bcodes = sbits <= 16;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (want_bcodes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * W * 8 > free_b / 3) want_bcodes = false;
+    if (knobs.mih_bcodes >= 0) want_bcodes = knobs.mih_bcodes != 0;
+  }
+  auto dalloc = [&](void** p, size_t bytes) -> int {
+    hipError_t r = hipMalloc(p, std::max<size_t>(bytes, 256));
+    if (r != hipSuccess) {
+      if (err) *err = std::string("index load: ") + hipGetErrorString(r);
+      return r == hipErrorOutOfMemory ? VC_ERR_NOMEM : VC_ERR_HIP;
+    }
+    ix->allocs.push_back(*p);
+    return VC_OK;
+  };
+  for (uint32_t t = 0; t < m && rc == VC_OK; ++t) {
+    uint64_t th[2];
+    if (fread(th, sizeof th, 1, fh) != 1) { rc = VC_ERR_INVALID; if (err) *err = "index file is truncated"; break; }
+    const uint64_t expect = sbits == 32 ? th[0] + 1 : (1ull << sbits) + 1;
+    if (th[1] != expect || th[0] > n) { rc = VC_ERR_INVALID; if (err) *err = "index file is corrupt (table directory)"; break; }
+    VcTableView tv{};
+    uint32_t *ids = nullptr, *offsets = nullptr, *bitmap = nullptr, *blockrank = nullptr;
+    if ((rc = dalloc((void**)&ids, (size_t)std::max<uint64_t>(n, 1) * 4))) break;
+    if ((rc = dalloc((void**)&offsets, (size_t)th[1] * 4))) break;
+    if ((rc = dalloc((void**)&bitmap, (size_t)bm_words * 4))) break;
+    if ((rc = copy_in(fh, ids, (size_t)n * 4, s, buf, err))) break;
+    if ((rc = copy_in(fh, offsets, (size_t)th[1] * 4, s, buf, err))) break;
+    if ((rc = copy_in(fh, bitmap, (size_t)bm_words * 4, s, buf, err))) break;
+    if (sbits == 32) {
+      if ((rc = dalloc((void**)&blockrank, (size_t)(1u << 24) * 4))) break;
+      if ((rc = copy_in(fh, blockrank, (size_t)(1u << 24) * 4, s, buf, err))) break;
+    }
+    tv.ids = ids; tv.offsets = offsets; tv.bitmap = bitmap; tv.blockrank = blockrank; tv.n_unique = (uint32_t)th[0];
+    if (want_bcodes && n) {
+      uint64_t* bc = nullptr;
+      if ((rc = dalloc((void**)&bc, (size_t)n * W * 8))) break;
+      hipLaunchKernelGGL(mih_bcodes_kernel, dim3(grid_for(n * W, n_cu)), dim3(256), 0, s, d_cols, stride, W, ids, n, bc);
+      tv.bcodes = bc;
+    }
+    ix->h_tables[t] = tv;
+  }
+  fclose(fh);
+  if (rc == VC_OK) {
+    hipError_t r = hipMalloc((void**)&ix->d_tables, sizeof(VcTableView) * m);
+    if (r == hipSuccess) r = hipMemcpyAsync(ix->d_tables, ix->h_tables.data(), sizeof(VcTableView) * m, hipMemcpyHostToDevice, s);
+    if (r == hipSuccess) r = hipStreamSynchronize(s);
+    if (r != hipSuccess) {
+      if (err) *err = std::string("index load: ") + hipGetErrorString(r);
+      rc = VC_ERR_HIP;
+    }
+  }
+  if (rc != VC_OK) {
+    vc_mih_free(ix);
+    return rc;
+  }
+  *out = ix;
+  return VC_OK;
+}
+
 // ---- search -------------------------------------------------------------------------------------------
 static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, MihState* st, std::string* err) {
   const size_t Q = MIH_QTILE;

@@ -27,7 +27,7 @@ EXPORTS = [
     "vc_size", "vc_get_code", "vc_build_index", "vc_get_bucket", "vc_bitmap_test", "vc_bitmap_read", "vc_search_knn",
     "vc_search_knn_dev", "vc_search_radius", "vc_merge_topk_dev", "vc_get_timing", "vc_set_stream",
     "vc_load_code_file", "vc_save_code_file", "vc_write_bitmap_file", "vc_device_status",
-    "vc_search_radius_dev",
+    "vc_search_radius_dev", "vc_read_bitmap_file", "vc_save_index", "vc_load_index",
 ]
 
 
@@ -104,6 +104,9 @@ def load_library():
     L.vc_load_code_file.argtypes = [vp, C.c_char_p, u64, C.POINTER(u64)]
     L.vc_save_code_file.argtypes = [vp, C.c_char_p]
     L.vc_write_bitmap_file.argtypes = [vp, u32, C.c_char_p]
+    L.vc_read_bitmap_file.argtypes = [vp, u32, C.c_char_p, C.POINTER(u64)]
+    L.vc_save_index.argtypes = [vp, C.c_char_p]
+    L.vc_load_index.argtypes = [vp, C.c_char_p]
     L.vc_get_timing.argtypes = [vp, C.POINTER(VcTiming)]
     L.vc_set_stream.argtypes = [vp, vp]
     L.vc_device_status.argtypes = [vp, C.POINTER(u32)]
@@ -192,6 +195,19 @@ class Engine:
     def write_bitmap_file(self, table, path):
         """raw LSB-first uint32 words of one table's occupancy bitmap (generate_bitmap.cc:122-125 format)"""
         self._check(self._L.vc_write_bitmap_file(self._h, table, os.fsencode(path)))
+
+    def read_bitmap_file(self, table, path):
+        """checks a generate_bitmap.cc-format file against the index's bitmap; returns the number of differing words
+        (0 = the file belongs to this database); raises for unreadable / wrongly sized files"""
+        bad = C.c_uint64()
+        self._check(self._L.vc_read_bitmap_file(self._h, table, os.fsencode(path), C.byref(bad)), ok=(VC_OK, VC_ERR_STATE))
+        return bad.value
+
+    def save_index(self, path):
+        self._check(self._L.vc_save_index(self._h, os.fsencode(path)))
+
+    def load_index(self, path):
+        self._check(self._L.vc_load_index(self._h, os.fsencode(path)))
 
     def __len__(self):
         n = C.c_uint64()

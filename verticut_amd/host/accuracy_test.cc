@@ -49,7 +49,12 @@ int main(int argc, char** argv) {
   if (!binary_bits || !substr_len || binary_bits % substr_len || k <= 0 || !image_count) return 2;
   const uint32_t nbytes = binary_bits / 8;
   try {
-    vc::Engine engine(binary_bits, binary_bits / substr_len, image_count);
+    // VC_REF_QUIRKS=1: behave exactly like the reference for substrings < 32 bit and fewer than 4 tables -- binaryToInt's
+    // sign-extended bucket keys (Pilaf/image_tools.h:13) and the stop rule's literal 4 (search_worker.cc:204).  Default:
+    // masked keys and min(n_tables, 4), which are exact where the reference is not.
+    const char* quirks = getenv("VC_REF_QUIRKS");
+    const uint32_t flags = (quirks && atoi(quirks)) ? (VC_FLAG_REF_SIGNEXT_KEYS | VC_FLAG_REF_STOP_LITERAL4) : 0u;
+    vc::Engine engine(binary_bits, binary_bits / substr_len, image_count, flags);
     uint64_t loaded = 0;
     engine.check(vc_load_code_file(engine.handle(), argv[1], image_count, &loaded));
     engine.check(vc_build_index(engine.handle()));

@@ -15,7 +15,8 @@
 //                distributed_image_search.cc:116) and print "id : dist" lines (:70-72 format);
 //                < 0: read queries from query_file (raw codes, at most 200: :83-84) and print the
 //                "Averate result" line of :87-93
-// Set VC_PRINT_RESULTS=1 to print the "id : dist" lines for file queries too.
+// Set VC_PRINT_RESULTS=1 to print the "id : dist" lines for file queries too; VC_REF_QUIRKS=1 reproduces the reference's
+// behaviour for substrings < 32 bit / fewer than 4 tables (sign-extended keys, literal-4 stop rule).
 // ============================================================================
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,7 +51,12 @@ int main(int argc, char** argv) {
   const bool print_results = getenv("VC_PRINT_RESULTS") != nullptr;
 
   try {
-    vc::Engine engine(binary_bits, binary_bits / substr_len, image_count);
+    // VC_REF_QUIRKS=1: behave exactly like the reference for substrings < 32 bit and fewer than 4 tables -- binaryToInt's
+    // sign-extended bucket keys (Pilaf/image_tools.h:13) and the stop rule's literal 4 (search_worker.cc:204).  Default:
+    // masked keys and min(n_tables, 4), which are exact where the reference is not.
+    const char* quirks = getenv("VC_REF_QUIRKS");
+    const uint32_t flags = (quirks && atoi(quirks)) ? (VC_FLAG_REF_SIGNEXT_KEYS | VC_FLAG_REF_STOP_LITERAL4) : 0u;
+    vc::Engine engine(binary_bits, binary_bits / substr_len, image_count, flags);
     // ---- load: build_hash_tables.cc:40-70 (records in file order, id = ordinal)
     FILE* fh = fopen(code_file, "rb");
     if (!fh) {
