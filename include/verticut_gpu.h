@@ -88,7 +88,8 @@ typedef struct vc_config {
   uint32_t cand_cap;     /* per-query candidate ring entries, 0 = default (65536) */
   uint32_t scan_blocks;  /* 0 = default grid for the verify kernel (tuning knob) */
   uint32_t query_tile;   /* queries verified per DB pass; 0 = default (32).  8 = HBM-bound pass, see DESIGN.md 4.1 */
-  uint32_t reserved[5];
+  uint32_t timing_sample;/* with VC_FLAG_LEAN_TIMING: time only every N-th verify launch (0/1 = every launch) */
+  uint32_t reserved[4];
 } vc_config;
 
 /* Per-query statistics == SearchWorker::get_stat (search_worker.cc:24-30, search_worker.h:42-45). */

@@ -122,6 +122,116 @@ __global__ void __launch_bounds__(256, WPS) k(const uint64_t* __restrict__ qg, u
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+__device__ __forceinline__ uint32_t bcnt_acc_s(uint32_t x, uint32_t acc) {   // accumulator operand in an SGPR
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "s"(acc));
+  return r;
+}
+
+// fully unrolled over QT = 8 queries, "matching bits" form: operands are the COMPLEMENTED query words, the accumulate
+// chain starts at tau, so acc = tau + 128 - d and d <= tau <=> acc >= 128; the 8 chains are OR-reduced (v_or3).
+//   MODE 0: query words + tau in SGPRs (loaded once)   MODE 1: query words + tau in VGPRs (loaded once)
+//   MODE 2: query words from LDS with immediate offsets (ds_read_b128 per query), tau in SGPRs
+template <int MODE, int WPS>
+__global__ void __launch_bounds__(256, WPS) k2(const uint64_t* __restrict__ qg, uint32_t iters, uint32_t* out, unsigned long long* cyc) {
+  constexpr int U = 4, W = 2, QT = 8;
+  __shared__ __attribute__((aligned(16))) uint64_t sq[QT * W];
+  for (uint32_t i = threadIdx.x; i < QT * W; i += 256) sq[i] = ~qg[i];
+  __syncthreads();
+  u64x2 r[U][W];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      r[u][j].x = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1 + 64 * u + 7 * j) ^ (blockIdx.x * 0xD6E8FEB86659FD93ull);
+      r[u][j].y = 0xBF58476D1CE4E5B9ull * (threadIdx.x + 3 + 64 * u + 5 * j) ^ (blockIdx.x * 0x94D049BB133111EBull);
+    }
+  uint32_t nq[QT][2 * W], tau[QT];
+#pragma unroll
+  for (int q = 0; q < QT; ++q) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const uint64_t v = ~qg[q * W + j];
+      nq[q][2 * j] = (uint32_t)v;
+      nq[q][2 * j + 1] = (uint32_t)(v >> 32);
+      if (MODE == 0) {
+        nq[q][2 * j] = __builtin_amdgcn_readfirstlane(nq[q][2 * j]);
+        nq[q][2 * j + 1] = __builtin_amdgcn_readfirstlane(nq[q][2 * j + 1]);
+      }
+    }
+    tau[q] = 3;
+    if (MODE != 1) tau[q] = __builtin_amdgcn_readfirstlane(tau[q] + (qg[0] == 1));
+    if (MODE == 1) asm volatile("" : "+v"(tau[q]));
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+#pragma unroll
+      for (int j = 0; j < 2 * W; ++j) asm volatile("" : "+v"(nq[q][j]));
+  }
+  uint32_t hits = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < W; ++j) asm volatile("" : "+v"(r[u][j]));
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      uint32_t w[2 * W];
+      if (MODE == 2) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&sq[q * W]);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2 * W; ++j) w[j] = nq[q][j];
+      }
+      uint32_t orv = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t da, db;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const uint32_t xal = (uint32_t)r[u][j].x ^ w[2 * j], xah = (uint32_t)(r[u][j].x >> 32) ^ w[2 * j + 1];
+          const uint32_t xbl = (uint32_t)r[u][j].y ^ w[2 * j], xbh = (uint32_t)(r[u][j].y >> 32) ^ w[2 * j + 1];
+          if (j == 0) {
+            da = MODE == 1 ? bcnt_acc(xal, tau[q]) : bcnt_acc_s(xal, tau[q]);
+            db = MODE == 1 ? bcnt_acc(xbl, tau[q]) : bcnt_acc_s(xbl, tau[q]);
+          } else {
+            da = bcnt_acc(xal, da);
+            db = bcnt_acc(xbl, db);
+          }
+          da = bcnt_acc(xah, da);
+          db = bcnt_acc(xbh, db);
+        }
+        orv |= da | db;
+      }
+      if (__ballot(orv >= 128u) != 0) hits += q + 1;
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * 256 + threadIdx.x] = hits;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE, int WPS>
+void run2(const char* name, const uint64_t* dq, uint32_t* dout, unsigned long long* dcyc) {
+  const uint32_t iters = 400, blocks = 256 * WPS, qt = 8;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL((k2<MODE, WPS>), dim3(blocks), dim3(256), 0, 0, dq, 10u, dout, dcyc);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k2<MODE, WPS>), dim3(blocks), dim3(256), 0, 0, dq, iters, dout, dcyc);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double units = (double)iters * qt;
+  const double ns = ms * 1e6 / units / WPS;
+  printf("%-34s qt=%2u waves/SIMD=%d  %.3f ms  %.1f ns per (query x 8-item tile) per SIMD = %.0f cyc @2.4GHz\n", name, qt, WPS, ms, ns, ns * 2.4);
+}
+
 template <int VARIANT, int WPS>
 void run(const char* name, const uint64_t* dq, uint32_t qt, uint32_t* dout, unsigned long long* dcyc) {
   const uint32_t iters = 400, blocks = 256 * WPS;
@@ -158,7 +268,14 @@ int main() {
   hipMemcpy(dq, hq, sizeof hq, hipMemcpyHostToDevice);
   hipMalloc(&dout, 256 * 8 * 256 * 4);
   hipMalloc(&dcyc, 4096 * 8);
-  for (uint32_t qt : {8u, 16u}) {
+  run2<0, 4>("U0 unrolled, SGPR queries", dq, dout, dcyc);
+  run2<1, 4>("U1 unrolled, VGPR queries", dq, dout, dcyc);
+  run2<2, 4>("U2 unrolled, LDS imm offsets", dq, dout, dcyc);
+  run2<0, 3>("U0 unrolled, SGPR, 3 waves/SIMD", dq, dout, dcyc);
+  run2<1, 3>("U1 unrolled, VGPR, 3 waves/SIMD", dq, dout, dcyc);
+  run2<0, 5>("U0 unrolled, SGPR, 5 waves/SIMD", dq, dout, dcyc);
+  run2<2, 5>("U2 unrolled, LDS, 5 waves/SIMD", dq, dout, dcyc);
+  for (uint32_t qt : {8u}) {
     run<0, 4>("0 as vc_scan (branch per query)", dq, qt, dout, dcyc);
     run<1, 4>("1 one branch per tile", dq, qt, dout, dcyc);
     run<2, 4>("2 bcnt only", dq, qt, dout, dcyc);

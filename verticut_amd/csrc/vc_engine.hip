@@ -30,6 +30,9 @@ struct vc_engine {
   uint64_t* d_out = nullptr;    size_t out_bytes = 0;     // [nq][k]
   uint32_t* d_cnt = nullptr;    size_t cnt_bytes = 0;     // [nq] result counts | [nq] raw ring counts
   uint32_t* d_rec = nullptr;                              // scratch of the device-side ring-overflow recovery (zero at first use)
+  // the last kernel of a linear step (vc_recover_kernel) hands the per-step state back zeroed: no memset per step
+  const uint32_t* clean_ptr = nullptr;  size_t clean_words = 0;
+  uint32_t scan_event_tick = 0;                           // VC_FLAG_LEAN_TIMING: only every timing_sample-th verify launch is timed
   VcKnobs knobs;                                          // environment knobs, read once at vc_create
 
   // timing: event pairs recorded since the last vc_get_timing (calls: whole search calls, scans: verify launches)
@@ -98,6 +101,7 @@ static void read_knobs(VcKnobs* k) {
   if (const char* r = getenv("VC_DEVICE_RECOVER")) k->device_recover = atoi(r) != 0;
   if (const char* v = getenv("VC_MIH_BCODES")) k->mih_bcodes = atoi(v) != 0;
   if (const char* v = getenv("VC_MIH_HOST_LOOP")) k->mih_host_loop = atoi(v);
+  if (const char* v = getenv("VC_SCAN_SMALL")) k->scan_small = atoi(v);
 }
 
 static int bind_device(vc_engine* e) {
@@ -562,8 +566,11 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
   p.limit = d_limit;
   p.wrap = e->knobs.scan_wrap;   // diagnostic build only, results are wrong by design
   p.diag = e->knobs.scan_diag;
-  hipEvent_t a, bb;
-  ev_pair(e, &a, &bb);
+  hipEvent_t a = nullptr, bb = nullptr;
+  // VC_FLAG_LEAN_TIMING with vc_config.timing_sample = N > 1: only every N-th verify launch is bracketed by events
+  // (an event record is a barrier packet, ~4-5 us each; a 125 M-code shard step is 0.35 ms)
+  const uint32_t every = (e->cfg.flags & VC_FLAG_LEAN_TIMING) ? std::max(e->cfg.timing_sample, 1u) : 1u;
+  if (e->scan_event_tick++ % every == 0) ev_pair(e, &a, &bb);
   if (a) VC_HIP(e, hipEventRecord(a, e->stream));
   VC_HIP(e, vc_launch_scan(p, e->W, e->n_cu, e->scan_blocks, &e->knobs, e->stream));
   if (a) {
@@ -574,10 +581,9 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
   return VC_OK;
 }
 
-// d_q: [nq][W] words on the device.  Results: d_out [nq][k] ascending (INF padded), d_cnt[0..nq) counts,
-// d_raw[0..nq) raw ring counts (> cap == the ring overflowed and the row is only an upper bound).
-static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_cnt,
-                        uint32_t* d_raw) {
+// d_q: [nq][W] words on the device.  Results: d_out [nq][k] ascending (INF padded), d_cnt[0..nq) counts
+// (UINT32_MAX == the ring overflowed, the device-side recovery did not run or gave up, and the row is only an upper bound).
+static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_cnt) {
   LinearBufs b;
   int rc = linear_bufs(e, nq, k, &b);
   if (rc) return rc;
@@ -596,7 +602,10 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
   for (uint32_t g0 = 0; g0 < nq; g0 += b.GQ) {
     const uint32_t gq = std::min(b.GQ, nq - g0);
     const uint64_t* dg = d_q + (size_t)g0 * e->W;
-    VC_HIP(e, hipMemsetAsync(e->d_state, 0, b.state_words * 4, e->stream));
+    // per-step state: zero from the previous step's last kernel, or (first use, new buffer, after an error) memset now
+    const bool clean = e->knobs.device_recover && e->clean_ptr == e->d_state && e->clean_words >= b.state_words;
+    e->clean_ptr = nullptr;
+    if (!clean) VC_HIP(e, hipMemsetAsync(e->d_state, 0, e->state_bytes, e->stream));
     VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dg, gq, b.d_shist, b.hs, k, e->bits, b.d_tau, VC_QUERY_LINE_WORDS, false,
                                     e->n_cu, e->knobs.sample_blocks_per_cu, e->stream));
     if (sample2)
@@ -612,9 +621,12 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
         VC_HIP(e, vc_launch_recover(e->d_cols, e->stride, e->n, e->W, e->cfg.id_base, e->bits, dg + (size_t)c0 * e->W, std::min(64u, gq - c0), k,
                                     e->d_ring + (size_t)c0 * b.cap, b.cap, b.d_count + (size_t)c0 * VC_QUERY_LINE_WORDS,
                                     b.d_hist + (size_t)c0 * b.hs, b.hs, VC_QUERY_LINE_WORDS, e->d_rec, d_out + (size_t)(g0 + c0) * k,
-                                    d_cnt + g0 + c0, e->n_cu, e->stream));
-    if (d_raw)   // one counter per 128-byte line -> dense
-      VC_HIP(e, hipMemcpy2DAsync(d_raw + g0, 4, b.d_count, VC_QUERY_LINE_WORDS * 4, 4, gq, hipMemcpyDeviceToDevice, e->stream));
+                                    d_cnt + g0 + c0, b.d_tau + (size_t)c0 * VC_QUERY_LINE_WORDS, b.d_shist + (size_t)c0 * b.hs,
+                                    (uint64_t)b.GQ * b.hs, 2 * VC_SHIST_COPIES, e->n_cu, e->stream));
+    if (e->knobs.device_recover) {
+      e->clean_ptr = e->d_state;
+      e->clean_words = e->state_bytes / 4;
+    }
   }
   return VC_OK;
 }
@@ -635,6 +647,7 @@ static int linear_recover(vc_engine* e, const uint64_t* d_q, uint32_t k, const s
   LinearBufs b;
   int rc = linear_bufs(e, (uint32_t)over.size(), k, &b);
   if (rc) return rc;
+  e->clean_ptr = nullptr;   // this path memsets the state itself and leaves it used
   const size_t W = e->W;
   uint64_t *d_rq = nullptr, *d_lim = nullptr, *d_rout = nullptr;
   uint32_t* d_rcnt = nullptr;
@@ -733,7 +746,7 @@ int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t
   if ((rc = grow(e, &e->d_cnt, &e->cnt_bytes, (size_t)nq * 8))) { e->stream = saved; return rc; }
   timing_begin(e);
   if (mode == VC_MODE_LINEAR) {
-    rc = linear_batch(e, (const uint64_t*)d_queries, nq, k, d_out, d_counts ? d_counts : e->d_cnt, nullptr);
+    rc = linear_batch(e, (const uint64_t*)d_queries, nq, k, d_out, d_counts ? d_counts : e->d_cnt);
   } else {
     rc = vc_mih_search(e->mih, e->d_cols, e->stride, e->n, (const uint64_t*)d_queries, nq, k, mode == VC_MODE_MIH_APPROX,
                        d_out, d_counts ? d_counts : e->d_cnt, nullptr, e->stream, &e->err);
@@ -758,7 +771,7 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
   std::vector<vc_query_stats> st;
   timing_begin(e);
   if (mode == VC_MODE_LINEAR) {
-    rc = linear_batch(e, e->d_q, nq, k, e->d_out, e->d_cnt, e->d_cnt + nq);
+    rc = linear_batch(e, e->d_q, nq, k, e->d_out, e->d_cnt);
   } else {
     st.resize(nq);
     rc = vc_mih_search(e->mih, e->d_cols, e->stride, e->n, e->d_q, nq, k, mode == VC_MODE_MIH_APPROX, e->d_out,
@@ -767,7 +780,7 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
   timing_end(e);
   if (rc) return rc;
   VC_HIP(e, hipMemcpyAsync(out, e->d_out, (size_t)nq * k * 8, hipMemcpyDeviceToHost, e->stream));
-  VC_HIP(e, hipMemcpyAsync(cnt.data(), e->d_cnt, (mode == VC_MODE_LINEAR ? 2 : 1) * (size_t)nq * 4, hipMemcpyDeviceToHost, e->stream));
+  VC_HIP(e, hipMemcpyAsync(cnt.data(), e->d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, e->stream));
   VC_HIP(e, hipStreamSynchronize(e->stream));
   if (mode == VC_MODE_LINEAR) {
     // a row still flagged here overflowed its ring and was not recomputed on the device (VC_DEVICE_RECOVER=0, or the

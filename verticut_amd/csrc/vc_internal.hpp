@@ -14,6 +14,7 @@ struct VcKnobs {
   bool mih_trace = false;                     // VC_MIH_TRACE
   bool device_recover = true;                 // VC_DEVICE_RECOVER=0: ring overflow handled by the host-driven fallback only
   int mih_bcodes = -1;                        // VC_MIH_BCODES: -1 auto, 0 / 1 forced
+  int scan_small = 1;                         // VC_SCAN_SMALL=0: the general (LDS-streamed) query loop for every tile size
   int mih_host_loop = 0;                      // VC_MIH_HOST_LOOP=1: one host round trip per shell (the round-1 loop)
 };
 
@@ -23,6 +24,7 @@ struct VcScanShape {
   int blk;      // 256 or 512
   int unroll;   // U
   int dbuf;     // register buffers per lane: 1 (rely on other waves), 2 (prefetch next chunk), 3 (two chunks ahead)
+  int small;    // tiles of <= 8 queries use the compile-time-unrolled form of the kernel
   uint64_t chunk_items() const { return 2ull * blk * unroll; }
 };
 VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes, const VcKnobs* knobs);
@@ -54,12 +56,15 @@ hipError_t vc_launch_select_ring_list(const uint64_t* d_buf, uint32_t cap, const
                                       uint32_t n_list, uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s);
 // Exact device-side recovery of the rows whose ring overflowed (count > cap), after vc_launch_select_ring on the same
 // buffers: no-op launch when nothing overflowed.  d_scratch: vc_recover_scratch_words() words, zero at first use
-// (the kernel restores its barrier words itself).  nq <= 64.
+// (the kernel restores its barrier words itself).  nq <= 64.  clean_copies > 0: as the last kernel of the step it also
+// zeroes the step's state for these queries (ring cursors d_count, thresholds d_clean_tau, d_hist, and clean_copies
+// partial histograms d_clean_shist + c * clean_copy_stride), so that the next step needs no memset.
 size_t vc_recover_scratch_words();
 hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t id_base, uint32_t bits,
                              const uint64_t* d_queries, uint32_t nq, uint32_t k, uint64_t* d_ring, uint32_t cap,
                              const uint32_t* d_count, const uint32_t* d_hist, uint32_t hist_stride, uint32_t qs, uint32_t* d_scratch,
-                             uint64_t* d_out, uint32_t* d_out_count, uint32_t n_cu, hipStream_t s);
+                             uint64_t* d_out, uint32_t* d_out_count, uint32_t* d_clean_tau, uint32_t* d_clean_shist,
+                             uint64_t clean_copy_stride, uint32_t clean_copies, uint32_t n_cu, hipStream_t s);
 // n_lists x [nq][k] sorted lists -> merged top-k
 hipError_t vc_launch_select_lists(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* d_out,
                                   uint32_t* d_out_count, hipStream_t s);

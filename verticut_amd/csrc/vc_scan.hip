@@ -34,6 +34,10 @@
 #define VC_SCAN_QUERY_PREFETCH 1
 #endif
 // ring-fill stride at which the chip-wide threshold is re-derived from the histogram
+// waves per SIMD the small-tile form (<= 8 queries, <= 128-bit codes) is compiled for
+#ifndef VC_SCAN_SMALL_WAVES
+#define VC_SCAN_SMALL_WAVES 4
+#endif
 #ifndef VC_SCAN_RECUT_EVERY
 #define VC_SCAN_RECUT_EVERY 32u
 #endif
@@ -365,12 +369,21 @@ __device__ __forceinline__ void vc_tile_wait(vc_u64x2 (&r)[U][W]) {
     for (int j = 0; j < W; ++j) asm volatile("" : "+v"(r[u][j]));
 }
 
-template <int W, int U, int BLK, int NB>
-__global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : ((W >= 4 || NB * U * W > 16) ? 3 : VC_SCAN_MIN_WAVES))) vc_scan_kernel(const VcScanParams p) {
+// QT > 0: the "small tile" form for p.qt <= QT <= 8 queries (the HBM-bound passes): the query loop is unrolled at compile
+// time, the LDS query words are read at immediate offsets (no address arithmetic, no loop branch, no second register
+// set for a software pipeline), and the distances are tested in "matching bits" form: the staged words are the
+// COMPLEMENTED query words and each item's accumulate chain starts at tau, so acc = tau + B - dist and
+// dist <= tau <=> acc >= B; the 2*U chains of a tile are OR-reduced (v_or3_b32) and tested with one compare -- B is a
+// power of two and acc < 2B, so the OR is >= B exactly when some chain is.  69 VALU instructions per query and 8-item
+// tile instead of 74 and no per-query loop overhead: 2.5-3.5 % off a whole pass at 8 queries (profiles/r02_sweeps.md).
+// (Compiling it for a fifth wave per SIMD -- <= 96 VGPRs, MINW = 5 -- spills into the loop, and a spill reload waits
+// vmcnt(0), i.e. for the prefetched tile: no gain, and unsafe next to hand-issued loads.)
+template <int W, int U, int BLK, int NB, int QT = 0, int MINW = 0>
+__global__ void __launch_bounds__(BLK, MINW ? MINW : (BLK == 512 ? 2 : ((W >= 4 || NB * U * W > 16) ? 3 : VC_SCAN_MIN_WAVES))) vc_scan_kernel(const VcScanParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* sq = (uint64_t*)smem;                             // [qt][W]  query tile
-  uint32_t* st = (uint32_t*)(smem + (size_t)p.qt * W * 8);    // [qt]     block-local copy of tau
-  for (uint32_t i = threadIdx.x; i < p.qt * W; i += BLK) sq[i] = p.queries[i];
+  uint32_t* st = (uint32_t*)(smem + (size_t)(QT ? QT : p.qt) * W * 8);    // [qt]     block-local copy of tau (QT > 0: p.qt == QT)
+  for (uint32_t i = threadIdx.x; i < p.qt * W; i += BLK) sq[i] = QT ? ~p.queries[i] : p.queries[i];
   for (uint32_t i = threadIdx.x; i < p.qt; i += BLK) st[i] = (VC_SCAN_DIAGNOSTICS && p.wrap) ? 0u : vc_ld_relaxed(p.tau + (size_t)i * p.qs);  // wrap: rare path off
   __syncthreads();
 
@@ -446,7 +459,51 @@ __global__ void __launch_bounds__(BLK, (BLK == 512 ? 2 : ((W >= 4 || NB * U * W 
     for (int j = 0; j < W; ++j) qw[j] = sq[q * W + j];
     t = st[q];
   };
+  // small-tile form of one query (QT > 0): w = complemented query words, t = tau; true iff some lane of the wave has an
+  // item within tau
+  auto one_query_c = [&](const vc_u64x2(&r)[U][W], const uint32_t(&w)[2 * W], uint32_t t) -> bool {
+    uint32_t orv = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint32_t da = t, db = t;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        da = vc_bcnt_acc((uint32_t)r[u][j].x ^ w[2 * j], da);
+        db = vc_bcnt_acc((uint32_t)r[u][j].y ^ w[2 * j], db);
+        da = vc_bcnt_acc((uint32_t)(r[u][j].x >> 32) ^ w[2 * j + 1], da);
+        db = vc_bcnt_acc((uint32_t)(r[u][j].y >> 32) ^ w[2 * j + 1], db);
+      }
+      orv |= da | db;
+    }
+    return __ballot(orv >= 64u * W) != 0;
+  };
   auto verify = [&](const vc_u64x2(&r)[U][W], uint64_t chunk) {
+    if constexpr (QT > 0) {   // exactly QT queries (p.qt == QT): no guards, no loop
+      const uint32_t* sw = (const uint32_t*)sq;
+      uint32_t hm = 0;   // wave-uniform mask of the queries with a candidate in this tile: ONE rare-path copy behind the loop
+      uint32_t wq[2][2 * W], tq[2];   // the LDS reads of query q + 1 are in flight while query q is verified
+#pragma unroll
+      for (int j = 0; j < 2 * W; ++j) wq[0][j] = sw[j];
+      tq[0] = st[0];
+#pragma unroll
+      for (int q = 0; q < QT; ++q) {
+        if (q + 1 < QT) {
+#pragma unroll
+          for (int j = 0; j < 2 * W; ++j) wq[(q + 1) & 1][j] = sw[(q + 1) * 2 * W + j];
+          tq[(q + 1) & 1] = st[q + 1];
+        }
+        if (one_query_c(r, wq[q & 1], tq[q & 1])) hm |= 1u << q;
+      }
+      while (hm) {
+        const uint32_t q = (uint32_t)__builtin_ctz(hm);
+        hm &= hm - 1u;
+        uint64_t qw[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) qw[j] = ~sq[q * W + j];
+        vc_scan_slow<W, U, BLK>(rare, r, qw, q, chunk * CH, st);
+      }
+      return;
+    }
 #if VC_SCAN_QUERY_PREFETCH
     uint64_t qa[W], qb[W];
     uint32_t ta, tb;
@@ -775,6 +832,13 @@ struct VcRecoverParams {
   uint64_t* out;             // [nq][k]
   uint32_t* out_count;       // [nq]
   uint32_t nq, k, cap, hist_stride, qs, bits, id_base;
+  // per-step state this launch hands back zeroed (the next search call then needs no memset): ring cursors and
+  // thresholds (one line per query), the scan's distance histogram, the bootstrap's partial histograms
+  uint32_t* clean_count;     // [nq] lines of qs words
+  uint32_t* clean_tau;       // [nq] lines of qs words
+  uint32_t* clean_shist;     // clean_copies x [.. nq rows of hist_stride ..], copy stride clean_copy_stride words
+  uint64_t clean_copy_stride;
+  uint32_t clean_copies;     // 0 = leave the state alone
 };
 
 // cut of a histogram plus the cumulative count below the cut bin (one wave; same result in every lane)
@@ -853,7 +917,23 @@ __global__ void __launch_bounds__(256, 2) vc_recover_kernel(const VcRecoverParam
   }
   __syncthreads();
   const uint32_t n_over = s_nover;
-  if (n_over == 0) return;
+  // Last kernel of a search step: hand the step's state back zeroed.  Nothing reads it any more once the overflow
+  // list is known (no overflow), or once the last round's barriers are behind (below).
+  auto clean_state = [&]() {
+    if (p.clean_copies == 0) return;
+    const uint64_t gtid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = gtid; i < (uint64_t)p.nq * p.qs; i += gsz) {
+      const_cast<uint32_t*>(p.count)[i] = 0;
+      p.clean_tau[i] = 0;
+    }
+    const uint64_t row = (uint64_t)p.nq * p.hist_stride;
+    for (uint64_t i = gtid; i < row; i += gsz) const_cast<uint32_t*>(p.hist)[i] = 0;
+    for (uint64_t i = gtid; i < row * p.clean_copies; i += gsz) p.clean_shist[(i / row) * p.clean_copy_stride + i % row] = 0;
+  };
+  if (n_over == 0) {
+    clean_state();
+    return;
+  }
 
   uint32_t epoch = 0;
   bool alive = true;
@@ -1005,6 +1085,7 @@ __global__ void __launch_bounds__(256, 2) vc_recover_kernel(const VcRecoverParam
   }
   // the last block to leave restores the barrier words (and records a give-up once)
   __syncthreads();
+  clean_state();
   if (threadIdx.x == 0) {
     __threadfence();
     if (atomicAdd(&p.bar[64], 1u) == gridDim.x - 1) {
@@ -1037,6 +1118,32 @@ uint32_t resident_grid(K kernel, int blk, size_t lds, uint32_t n_cu, uint32_t wa
 
 template <int W>
 hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t lds, uint32_t n_cu, uint32_t want, hipStream_t s) {
+#define VC_LAUNCH_QT(NB_, U_, QT_, MW_)                                                                     \
+  {                                                                                                         \
+    auto kern = vc_scan_kernel<W, U_, 256, NB_, QT_, MW_>;                                                  \
+    const size_t lds_q = (size_t)QT_ * (W * 8 + 4);                                                         \
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nchunks, resident_grid(kern, 256, lds_q, n_cu, want)); \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_q, s, p);                                           \
+    return hipGetLastError();                                                                               \
+  }
+  // small tiles (<= 8 queries; the diagnostic knobs keep the general form): compile-time query loop, one kernel per count
+  if (sh.small && sh.blk == 256 && sh.dbuf == 2 && p.qt <= 8 && !(VC_SCAN_DIAGNOSTICS && (p.wrap || p.diag))) {
+    constexpr int UD = W <= 2 ? 4 : (W <= 4 ? 2 : 1);
+    constexpr int MW = W <= 2 ? VC_SCAN_SMALL_WAVES : 0;
+    if (sh.unroll == UD) {
+      switch (p.qt) {
+        case 1: VC_LAUNCH_QT(2, UD, 1, MW)
+        case 2: VC_LAUNCH_QT(2, UD, 2, MW)
+        case 3: VC_LAUNCH_QT(2, UD, 3, MW)
+        case 4: VC_LAUNCH_QT(2, UD, 4, MW)
+        case 5: VC_LAUNCH_QT(2, UD, 5, MW)
+        case 6: VC_LAUNCH_QT(2, UD, 6, MW)
+        case 7: VC_LAUNCH_QT(2, UD, 7, MW)
+        default: VC_LAUNCH_QT(2, UD, 8, MW)
+      }
+    }
+  }
+#undef VC_LAUNCH_QT
 #define VC_LAUNCH(NB_, U_, B_)                                                                              \
   {                                                                                                         \
     auto kern = vc_scan_kernel<W, U_, B_, NB_>;                                                             \
@@ -1075,6 +1182,7 @@ VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes, const
   // big LDS tiles leave room for one block per CU only: use 512 threads to keep 2 waves per SIMD.
   sh.blk = lds > 40 * 1024 ? 512 : 256;
   sh.dbuf = 2;
+  sh.small = knobs ? knobs->scan_small : 1;
   if (knobs && knobs->shape_set) {  // dev knob VC_SCAN_SHAPE "U,BLK,DB" (read at vc_create)
     const int u = knobs->shape_u ? knobs->shape_u : sh.unroll, b = knobs->shape_blk ? knobs->shape_blk : sh.blk, d = knobs->shape_db;
     if ((u == 1 || u == 2 || u == 4) && u * (int)W <= 8) sh.unroll = u;
@@ -1207,8 +1315,9 @@ size_t vc_recover_scratch_words() {   // idhist | rcount lines | barrier lines (
 hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t id_base, uint32_t bits,
                              const uint64_t* d_queries, uint32_t nq, uint32_t k, uint64_t* d_ring, uint32_t cap,
                              const uint32_t* d_count, const uint32_t* d_hist, uint32_t hist_stride, uint32_t qs, uint32_t* d_scratch,
-                             uint64_t* d_out, uint32_t* d_out_count, uint32_t n_cu, hipStream_t s) {
-  if (nq == 0 || n == 0) return hipSuccess;
+                             uint64_t* d_out, uint32_t* d_out_count, uint32_t* d_clean_tau, uint32_t* d_clean_shist,
+                             uint64_t clean_copy_stride, uint32_t clean_copies, uint32_t n_cu, hipStream_t s) {
+  if (nq == 0) return hipSuccess;
   if (nq > VC_REC_MAXQ) return hipErrorInvalidValue;
   VcRecoverParams p{};
   p.cols = cols; p.stride = stride; p.n = n; p.queries = d_queries; p.count = d_count; p.hist = d_hist; p.ring = d_ring;
@@ -1218,6 +1327,7 @@ hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, 
   p.gave_up = p.bar + 96;
   p.out = d_out; p.out_count = d_out_count;
   p.nq = nq; p.k = k; p.cap = cap; p.hist_stride = hist_stride; p.qs = qs; p.bits = bits; p.id_base = id_base;
+  p.clean_tau = d_clean_tau; p.clean_shist = d_clean_shist; p.clean_copy_stride = clean_copy_stride; p.clean_copies = clean_copies;
   const size_t lds = (size_t)VC_REC_RQ * VC_REC_BINS * 4;
 #define VC_REC_CASE(W_)                                                                                              \
   case W_: {                                                                                                         \

@@ -35,7 +35,7 @@ class VcConfig(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("bits", C.c_uint32), ("n_tables", C.c_uint32), ("flags", C.c_uint32),
         ("capacity", C.c_uint64), ("id_base", C.c_uint32), ("device", C.c_int32), ("cand_cap", C.c_uint32),
-        ("scan_blocks", C.c_uint32), ("query_tile", C.c_uint32), ("reserved", C.c_uint32 * 5),
+        ("scan_blocks", C.c_uint32), ("query_tile", C.c_uint32), ("timing_sample", C.c_uint32), ("reserved", C.c_uint32 * 4),
     ]
 
 
@@ -131,12 +131,12 @@ class Engine:
     """One HBM-resident shard of the code database plus its MIH index (one per GPU/process)."""
 
     def __init__(self, bits, capacity, n_tables=0, flags=0, id_base=0, device=-1, cand_cap=0, scan_blocks=0,
-                 query_tile=0):
+                 query_tile=0, timing_sample=0):
         self._L = load_library()
         self.bits, self.nbytes, self.n_tables, self.id_base = bits, bits // 8, n_tables, id_base
         cfg = VcConfig(abi_version=VC_ABI_VERSION, bits=bits, n_tables=n_tables, flags=flags, capacity=capacity,
                        id_base=id_base, device=device, cand_cap=cand_cap, scan_blocks=scan_blocks,
-                       query_tile=query_tile)
+                       query_tile=query_tile, timing_sample=timing_sample)
         h = C.c_void_p()
         rc = self._L.vc_create(C.byref(cfg), C.byref(h))
         if rc != VC_OK:
