@@ -52,6 +52,7 @@ def parse(argv=None):
     ap.add_argument("--queries", type=int, default=None, help="queries per step")
     ap.add_argument("--seed", type=int, default=34, help="linear_search.cc:105 srand(34)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--tables", default="2,4", help="workload c2: table counts to run (the first one is the line's value)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child run that measures roofline.traffic")
     args = ap.parse_args(argv)
@@ -442,7 +443,8 @@ def run_c2(args, env, emit):
     n, bits, Q, radius = int(args.n), args.bits, args.queries, 8
     rng = np.random.default_rng(args.seed + 2)
     lines = {}
-    for m in (2, 4):
+    tables = [int(t) for t in args.tables.split(",")]
+    for m in tables:
         e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
         e.add_synthetic(n, seed=args.seed)
         t0 = time.perf_counter()
@@ -481,26 +483,28 @@ def run_c2(args, env, emit):
         }
         e.close()
     ok = all(v["results_check"] == "ok" for v in lines.values())
+    m0 = tables[0]
     line = {
         "metric": "queries/sec (all neighbours within Hamming distance 8, MIH) on 64-bit codes, 100M DB; bit-exact vs linear scan",
-        "value": lines[2]["value"], "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": lines[2]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": lines[m0]["value"], "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": lines[m0]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1]: %d-bit codes, %.3g-code DB, MIH r=8 neighbour search, m=2 x 32-bit substrings "
-                        "(value); m=4 x 16-bit as variant" % (bits, n),
+            "workload": "BASELINE configs[1]: %d-bit codes, %.3g-code DB, MIH r=8 neighbour search, m=%d x %d-bit substrings "
+                        "(value)%s" % (bits, n, m0, bits // m0, "; m=4 x 16-bit as variant" if len(tables) > 1 else ""),
             "n_codes": n, "bits": bits, "radius": radius, "queries_per_step": Q, "seed": args.seed,
             "query_kind": "DB item with 0-8 random bit flips (query-by-image-id use, image_search_client.h:23-25)",
             "api": "vc_search_radius_dev: queries, results and offsets resident in HBM",
-            "index_build_s": lines[2]["index_build_s"], "mean_neighbours_per_query": lines[2]["mean_neighbours"],
-            "variants": {"m4_s16": {"value": lines[4]["value"], "ms_per_step": lines[4]["ms_per_step"],
-                                    "roofline": lines[4]["roofline"], "results_check": lines[4]["results_check"]}},
+            "index_build_s": lines[m0]["index_build_s"], "mean_neighbours_per_query": lines[m0]["mean_neighbours"],
+            "variants": {"m%d_s%d" % (m, bits // m): {"value": lines[m]["value"], "ms_per_step": lines[m]["ms_per_step"],
+                                                      "roofline": lines[m]["roofline"], "results_check": lines[m]["results_check"]}
+                         for m in tables[1:]},
         },
-        "roofline": lines[2]["roofline"],
+        "roofline": lines[m0]["roofline"],
         "results_check": "ok" if ok else "FAILED",
     }
     if args.cpu_seconds > 0:
-        line["cpu_baseline"] = cpu_baseline_mih(args, 2, "radius", radius=radius)
+        line["cpu_baseline"] = cpu_baseline_mih(args, m0, "radius", radius=radius)
     emit(line)
     return ok
 

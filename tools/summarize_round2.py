@@ -1,0 +1,106 @@
+"""Dev tool: turn one tools/profile_round2.sh output directory into the files committed under profiles/.
+usage: python tools/summarize_round2.py gpurun_out/<tag> profiles/<prefix>          (e.g. profiles/r02)
+Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB per dispatch; on gfx950 FETCH_SIZE counts a wide coalesced
+16 B/lane stream at half its bytes (MI355X_MICROARCH.md, HBM section) -> x 2 for the verify kernel's stream.  For the
+MIH query kernel's 4..64-byte gathers that correction is uncalibrated: both the raw figure and x 2 are recorded."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+
+
+def one(pattern):
+    files = glob.glob(pattern, recursive=True)
+    if len(files) != 1:
+        raise SystemExit("expected one file for %s, found %d" % (pattern, len(files)))
+    return files[0]
+
+
+def pmc(pass_dir, kernel):
+    """average counter value and duration per dispatch of `kernel` in one --pmc pass (first dispatch dropped: cold)"""
+    acc, dur = {}, {}
+    with open(one("%s/%s/**/*_counter_collection.csv" % (src, pass_dir))) as f:
+        for row in csv.DictReader(f):
+            if kernel not in row["Kernel_Name"]:
+                continue
+            acc.setdefault(row["Counter_Name"], {})[row["Dispatch_Id"]] = float(row["Counter_Value"])
+            dur[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+    ids = sorted(dur, key=int)[1:] or sorted(dur, key=int)
+    out = {k: sum(v[i] for i in ids) / len(ids) for k, v in acc.items()}
+    out["pass_avg_ms"] = sum(dur[i] for i in ids) / len(ids)
+    out["pass_launches"] = len(ids)
+    return out
+
+
+def bench(name):
+    with open("%s/bench_%s.json" % (src, name)) as f:
+        return json.load(f)
+
+
+def stats(name, dst):
+    shutil.copy(one("%s/stats_%s/**/*_kernel_stats.csv" % (src, name)), dst)
+
+
+# ---- headline
+b = bench("c3")
+json.dump(b, open(prefix + "_bench.json", "w"))
+stats("c3", prefix + "_bench_kernel_stats.csv")
+counters = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for k, v in pmc(d, "vc_scan_kernel").items():
+        counters[k if not k.startswith("pass_") else d + "_" + k] = v
+json.dump(counters, open(prefix + "_bench_pmc_scan_kernel.json", "w"), indent=1)
+cfg = b["config"]
+alg = cfg["n_codes"] * cfg["bits"] // 8
+hbm = (counters["FETCH_SIZE"] * 2 + counters["WRITE_SIZE"]) * 1024
+json.dump({
+    "kernel": "vc_scan_kernel", "n_codes": cfg["n_codes"], "bits": cfg["bits"], "query_tile": cfg["query_tile"],
+    "FETCH_SIZE_KB_per_launch": counters["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": counters["WRITE_SIZE"],
+    "correction": "FETCH_SIZE x 2 (wide coalesced 16 B/lane stream on gfx950), WRITE_SIZE as is; separate --pmc passes",
+    "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg,
+    "bench_line_traffic": b["roofline"].get("traffic"),
+}, open(prefix + "_scan_traffic.json", "w"), indent=1)
+print("c3: %.1f q/s, scan %.4f ms, frac %.3f, traffic/alg %.4f (bench line: %s)" % (
+    b["value"], b["roofline"]["avg_launch_ms"], b["roofline"]["frac"], hbm / alg, b["roofline"].get("traffic")))
+
+# ---- the other workloads
+for w in ("c2", "knn_mih", "c5shard"):
+    bw = bench(w)
+    json.dump(bw, open("%s_bench_%s.json" % (prefix, w), "w"))
+    stats(w, "%s_%s_kernel_stats.csv" % (prefix, w))
+    print("%s: %.1f q/s, %s %.4f ms/launch, frac %.3f, cpu %.1f q/s on %d threads" % (
+        w, bw["value"], bw["roofline"]["kernel"], bw["roofline"]["avg_launch_ms"], bw["roofline"]["frac"],
+        bw.get("cpu_baseline", {}).get("value", float("nan")), bw.get("cpu_baseline", {}).get("cores", 0)))
+
+# ---- MIH counters: effective traffic of mih_query_kernel next to the algorithmic bytes
+for w in ("c2", "knn_mih"):
+    bw = bench(w)
+    fetch = pmc("pmc_%s_fetch" % w, "mih_query_kernel")
+    tcc = pmc("pmc_%s_tcc" % w, "mih_query_kernel")
+    rl = bw["roofline"]
+    nq = bw["config"]["queries_per_step"]
+    launches_per_step = rl["launches"] / bw["steps"]
+    # with several launches per step (m = 2 and m = 4 engines in c2, tiles of 1024 in knn) the average is over all of them
+    raw = fetch["FETCH_SIZE"] * 1024
+    out = {
+        "kernel": "mih_query_kernel", "workload": bw["config"]["workload"],
+        "FETCH_SIZE_KB_per_launch": fetch["FETCH_SIZE"], "fetch_pass_avg_ms": fetch["pass_avg_ms"], "fetch_pass_launches": fetch["pass_launches"],
+        "TCC_HIT_sum_per_launch": tcc.get("TCC_HIT_sum"), "TCC_MISS_sum_per_launch": tcc.get("TCC_MISS_sum"),
+        "l2_hit_rate": (tcc["TCC_HIT_sum"] / (tcc["TCC_HIT_sum"] + tcc["TCC_MISS_sum"])) if tcc.get("TCC_HIT_sum") is not None else None,
+        "memory_side_bytes_per_launch_raw": raw, "memory_side_bytes_per_launch_x2": raw * 2,
+        "note": "FETCH_SIZE = TCC_EA0_RDREQ x 64 B; for 16-byte and 4-byte gathers the gfx950 x2 correction is uncalibrated, both given. "
+                "The counter passes of c2 ran the m = 2 engine only (--tables 2); the bench line's algorithmic bytes are m = 2's.",
+        "bench_algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"], "bench_per_query": rl["per_query"],
+        "launches_per_step": launches_per_step, "queries_per_step": nq,
+    }
+    json.dump(out, open("%s_mih_%s_pmc.json" % (prefix, w), "w"), indent=1)
+    print("%s pmc: FETCH %.0f KB/launch (raw %.1f MB), L2 hit rate %s, algorithmic %.1f MB/launch" % (
+        w, fetch["FETCH_SIZE"], raw / 1e6, out["l2_hit_rate"], rl["algorithmic_bytes_per_launch"] / 1e6))
+
+if os.path.exists("%s/shard/timeline.txt" % src):
+    shutil.copy("%s/shard/timeline.txt" % src, prefix + "_shard_timeline.txt")
+    shutil.copy("%s/shard/bench.json" % src, prefix + "_shard_bench.json")
