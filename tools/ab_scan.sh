@@ -1,6 +1,5 @@
 #!/bin/bash
 # Dev tool (GPU box): A/B of verify-kernel variants inside one gpurun call (boxes differ by up to 7 % in raw HBM rate).
-# usage: tools/ab_scan.sh <outfile> ; prints "label qps ms_per_step frac" per variant, 1e9 and 1.25e8 codes
 OUT=${1:-gpurun_out/ab_scan.txt}
 L=$GRAFT_REPO_ROOT/verticut_amd/lib
 run() {  # label, env...
@@ -10,8 +9,9 @@ run() {  # label, env...
     echo "$label n=$n  $r" | tee -a $OUT
   done
 }
-run "general-loop(r1)      " VC_SCAN_SMALL=0
-run "small w5 nb2          " VC_SCAN_SMALL=1
-run "small w4 nb2          " VERTICUT_GPU_LIB=$L/libverticut_gpu_w4.so
-run "general-loop(r1) again" VC_SCAN_SMALL=0
-run "small w5 nb2 again    " VC_SCAN_SMALL=1
+run "small nb2 w4          " VC_SCAN_SMALL=1
+run "small nb1 w8          " VC_SCAN_SHAPE=4,256,0
+run "small nb1 w6          " VC_SCAN_SHAPE=4,256,0 VERTICUT_GPU_LIB=$L/libverticut_gpu_w4.so
+run "general               " VC_SCAN_SMALL=0
+run "small nb2 w4 again    " VC_SCAN_SMALL=1
+run "small nb1 w8 again    " VC_SCAN_SHAPE=4,256,0

@@ -1130,7 +1130,7 @@ hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t ld
   if (sh.small && sh.blk == 256 && sh.dbuf == 2 && p.qt <= 8 && !(VC_SCAN_DIAGNOSTICS && (p.wrap || p.diag))) {
     constexpr int UD = W <= 2 ? 4 : (W <= 4 ? 2 : 1);
     constexpr int MW = W <= 2 ? VC_SCAN_SMALL_WAVES : 0;
-    if (sh.unroll == UD) {
+    if (sh.unroll == UD && sh.dbuf == 2) {
       switch (p.qt) {
         case 1: VC_LAUNCH_QT(2, UD, 1, MW)
         case 2: VC_LAUNCH_QT(2, UD, 2, MW)
