@@ -297,3 +297,60 @@ def test_queries_that_outlive_the_query_kernel_continue_in_the_multi_block_shell
         assert max(s.radius for s in st) > 4               # the hand-over really happened
         for s in st:                                       # n_sub_reads = every leaf of every shell searched (no bitmap attached)
             assert s.n_sub_reads == sum(__import__("math").comb(32, r) for r in range(s.radius + 1))
+
+
+@pytest.mark.parametrize("k", [2000, 8000])
+def test_mih_large_k(vc, oracle, k):
+    """k = 2000 still runs in the query kernel (top-k + candidates in a 4096-entry LDS buffer); k = 8000 exceeds what one
+    block keeps in LDS and takes the multi-block path from shell 0: both equal the canonical rule and the linear scan."""
+    n, bits, m = 60000, 128, 4
+    rng = np.random.default_rng(k)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=6, max_flips=6)     # ~10 K items per cluster
+    q = _near_queries(codes, 3, rng, 2)
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        e.build_index()
+        got, cnt, st = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        lin, _ = e.search_knn(q, k)
+        assert np.all(cnt == k) and np.array_equal(got >> SH, lin >> SH)
+        for i in range(len(q)):
+            exp, _ = _canonical_mih(oracle, codes, q[i], m, k, st[i].radius, False)
+            assert np.array_equal(got[i], exp)
+
+
+def test_radius_search_device_api(vc, oracle):
+    """vc_search_radius_dev: queries, results and offsets stay in HBM; same rows as the host API and numpy; a too small
+    output buffer is reported with the needed size in the offsets; more than one tile of queries."""
+    import torch
+    n, bits, m, radius = 80000, 64, 2, 8
+    rng = np.random.default_rng(4)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=300, max_flips=5)
+    q = _near_queries(codes, 1100, rng, 3)                      # two tiles of the query kernel (1024 + 76)
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        e.build_index()
+        host = e.search_radius(q, radius, mode=vc.MODE_MIH_EXACT, cap_per_query=1 << 12)
+        total = sum(len(r) for r in host)
+        dq = torch.from_numpy(q).cuda()
+        d_off = torch.zeros((len(q) + 1,), dtype=torch.int64, device="cuda")
+        d_out = torch.zeros((total + 10,), dtype=torch.int64, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        for mode in (vc.MODE_MIH_EXACT, vc.MODE_LINEAR):
+            rc = e.search_radius_dev(dq.data_ptr(), len(q), radius, d_out.data_ptr(), total + 10, d_off.data_ptr(), mode=mode, stream=s)
+            torch.cuda.synchronize()
+            assert rc == vc.VC_OK
+            off = d_off.cpu().numpy().view(np.uint64)
+            res = d_out.cpu().numpy().view(np.uint64)
+            assert int(off[-1]) == total
+            for i in (0, 1, 500, 1023, 1024, 1099):
+                assert np.array_equal(res[int(off[i]):int(off[i + 1])], host[i]), (mode, i)
+        for i in (0, 7, 1050):                                   # host rows against numpy
+            d = oracle.np_distances(codes, q[i])
+            ids = np.nonzero(d <= radius)[0]
+            assert np.array_equal(host[i], np.sort(oracle.pack(d[ids], ids.astype(np.uint64))))
+        small = torch.zeros((total // 2,), dtype=torch.int64, device="cuda")
+        rc = e.search_radius_dev(dq.data_ptr(), len(q), radius, small.data_ptr(), total // 2, d_off.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        assert rc == vc.VC_ERR_CAPACITY and int(d_off.cpu().numpy().view(np.uint64)[-1]) == total
+        t = e.timing()
+        assert t.mih_launches >= 4 and t.mih_queries >= 2 * len(q) and t.mih_probes > 0 and t.mih_ms > 0

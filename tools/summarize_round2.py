@@ -42,7 +42,12 @@ def bench(name):
 
 
 def stats(name, dst):
-    shutil.copy(one("%s/stats_%s/**/*_kernel_stats.csv" % (src, name)), dst)
+    """kernel-stats summary with the (very long) library kernel names cut to 110 characters"""
+    with open(one("%s/stats_%s/**/*_kernel_stats.csv" % (src, name))) as f, open(dst, "w", newline="") as g:
+        w = csv.writer(g, quoting=csv.QUOTE_MINIMAL)
+        for row in csv.reader(f):
+            row[0] = row[0][:110]
+            w.writerow(row)
 
 
 # ---- headline
