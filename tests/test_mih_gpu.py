@@ -354,3 +354,33 @@ def test_radius_search_device_api(vc, oracle):
         assert rc == vc.VC_ERR_CAPACITY and int(d_off.cpu().numpy().view(np.uint64)[-1]) == total
         t = e.timing()
         assert t.mih_launches >= 4 and t.mih_queries >= 2 * len(q) and t.mih_probes > 0 and t.mih_ms > 0
+
+
+@pytest.mark.parametrize("bits,m", [(128, 4), (64, 4)])
+def test_radius_search_with_huge_neighbourhoods(vc, oracle, bits, m):
+    """duplicate-heavy data: a query has 20 000+ neighbours inside the radius -- more than the query kernel keeps in LDS
+    (spill to the ring, unsorted), more than the default work ring of 4096 entries holds (the call doubles it and
+    repeats) and more than the LDS segment sort takes (8192: bitonic network on the segment in global memory); mixed
+    with queries that have a handful.  MIH == linear scan == numpy, ascending, through both APIs' shared path."""
+    n = 90000
+    rng = np.random.default_rng(bits)
+    base = oracle.gen_codes(4, bits, 3)
+    codes = base[rng.integers(0, 4, size=n)].copy()                      # ~22 500 copies of each of 4 codes
+    flip = rng.integers(0, n, size=n // 3)
+    codes[flip, rng.integers(0, bits // 8, size=len(flip))] ^= (1 << rng.integers(0, 8, size=len(flip))).astype(np.uint8)
+    codes[:300] = oracle.gen_codes(300, bits, 9)                          # a few loners
+    q = np.stack([base[0], codes[5], base[2], codes[100000 % n]])
+    q[2, 1] ^= 0x3
+    radius = 3
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        e.build_index()
+        mih = e.search_radius(q, radius, mode=vc.MODE_MIH_EXACT, cap_per_query=64)      # host buffer too small at first, too
+        lin = e.search_radius(q, radius, mode=vc.MODE_LINEAR, cap_per_query=64)
+        for i in range(len(q)):
+            d = oracle.np_distances(codes, q[i])
+            ids = np.nonzero(d <= radius)[0]
+            exp = np.sort(oracle.pack(d[ids], ids.astype(np.uint64)))
+            assert np.array_equal(mih[i], exp), i
+            assert np.array_equal(lin[i], exp), i
+        assert max(len(r) for r in mih) > 20000 and min(len(r) for r in mih) < 10

@@ -809,11 +809,11 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
 //
 // One persistent launch after every select: without an overflowed query each block reads the ring cursors and
 // leaves (a ~2 us launch); otherwise the passes are separated by grid barriers, so every block must be resident
-// (2 blocks of 256 threads per CU, 64 KiB of LDS each) and every spin is bounded: if the grid cannot meet (another
+// (2 blocks of 256 threads per CU, 32 KiB of LDS each -- 64 KiB only for k > 4096) and every spin is bounded: if the grid cannot meet (another
 // kernel holds the CUs for seconds) the blocks give up, the row keeps its UINT32_MAX count and the sticky
 // `gave_up` counter reports it (vc_device_status).
 // ------------------------------------------------------------------------------------------
-#define VC_REC_RQ 8u            // overflowed queries recovered per round of passes (they share the two full sweeps)
+#define VC_REC_RQ 4u            // overflowed queries recovered per round of passes (they share the two full sweeps)
 #define VC_REC_BINS 2048u
 #define VC_REC_MAXQ 64u         // = VC_GROUP_QUERIES: queries one select / recover launch serves
 #define VC_REC_SPIN_LIMIT (3u << 20)   // x s_sleep 32 (~0.9 us): ~3 s
@@ -1328,7 +1328,11 @@ hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, 
   p.out = d_out; p.out_count = d_out_count;
   p.nq = nq; p.k = k; p.cap = cap; p.hist_stride = hist_stride; p.qs = qs; p.bits = bits; p.id_base = id_base;
   p.clean_tau = d_clean_tau; p.clean_shist = d_clean_shist; p.clean_copy_stride = clean_copy_stride; p.clean_copies = clean_copies;
-  const size_t lds = (size_t)VC_REC_RQ * VC_REC_BINS * 4;
+  // block-local position histograms (32 KiB), reused as the sort buffer of the final rows (k entries, padded to a power
+  // of two); kept small so that the grids of several engines fit on the chip side by side
+  uint32_t kp = 2;
+  while (kp < k) kp <<= 1;
+  const size_t lds = std::max((size_t)VC_REC_RQ * VC_REC_BINS * 4, (size_t)kp * 8);
 #define VC_REC_CASE(W_)                                                                                              \
   case W_: {                                                                                                         \
     auto kern = vc_recover_kernel<W_>;                                                                               \
