@@ -421,6 +421,10 @@ def _near_queries(engine, n, nq, bits, max_flips, rng):
 
 def _mih_roofline(tm, bits):
     """bytes = probes x 4 (bitmap) + non-empty buckets x 16 (key lookup) + entries x (4 id + B/8 code)"""
+    if tm.mih_launches == 0:
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": "mih_probe_kernel", "note": "this shape (buckets of ~1500 entries) runs the multi-block shell kernels, "
+                "one launch sequence per shell; only mih_query_kernel is instrumented"}
     launches = max(tm.mih_launches, 1)
     alg = (tm.mih_probes * 4 + tm.mih_hits * 16 + tm.mih_entries * (4 + bits // 8)) / launches
     avg_ms = tm.mih_ms / launches

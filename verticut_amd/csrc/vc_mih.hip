@@ -1593,14 +1593,18 @@ static uint32_t binom_host(uint32_t n, uint32_t k) {
   return (uint32_t)r;
 }
 
-// last shell the one-block-per-query kernel runs: the shells beyond cost more than `budget` bucket probes per query
-// and go to the multi-block kernels (one launch sequence per shell)
-static uint32_t inblock_last_shell(uint32_t S, uint32_t m, uint64_t budget, uint32_t r_cap) {
+// last shell the one-block-per-query kernel runs: the shells beyond cost more than `budget` bucket probes per query,
+// or more than MQ_ENTRY_BUDGET expected bucket entries (probes x average bucket size: one block verifies them
+// serially, round after round; the multi-block kernels spread a shell of big buckets over the chip -- 64-bit codes,
+// 1e8 items, 16-bit substrings: 1526 entries per bucket, 274 K vs 160 K queries/s at configs[1]), and go to the
+// multi-block kernels (one launch sequence per shell)
+#define MQ_ENTRY_BUDGET 65536.0
+static uint32_t inblock_last_shell(uint32_t S, uint32_t m, uint64_t budget, uint32_t r_cap, double avg_bucket) {
   uint64_t tot = 0;
   uint32_t r_last = 0;
   for (uint32_t r = 0; r <= std::min(S, r_cap); ++r) {
     const uint64_t c = (uint64_t)m * binom_host(S, r);
-    if (r > 0 && tot + c > budget) break;
+    if (r > 0 && (tot + c > budget || (double)(tot + c) * avg_bucket > MQ_ENTRY_BUDGET)) break;
     tot += c;
     r_last = r;
   }
@@ -1635,7 +1639,8 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   uint32_t buf_entries = 1024;
   while (buf_entries < k + MQ_ROUND) buf_entries <<= 1;
   const bool inblock = ix->knobs.mih_host_loop == 0 && buf_entries <= 8192 && ix->m <= 64;
-  const uint32_t r_last = inblock_last_shell(S, ix->m, MQ_KNN_BUDGET, S);
+  const double avg_bucket = (double)ix->n / (S >= 32 ? 4294967296.0 : (double)(1ull << S));
+  const uint32_t r_last = inblock_last_shell(S, ix->m, MQ_KNN_BUDGET, S, avg_bucket);
   const bool trace = ix->knobs.mih_trace;   // VC_MIH_TRACE: per-shell wall times on stderr
 
   for (uint32_t q0 = 0; q0 < nq; q0 += MIH_QTILE) {
@@ -1760,7 +1765,8 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
   if (use_mih && ix->knobs.mih_host_loop == 0) {
     uint64_t probes = 0;
     for (uint32_t r = 0; r <= rsub; ++r) probes += (uint64_t)ix->m * binom_host(ix->sbits, r);
-    inblock = probes <= MQ_RADIUS_BUDGET && rsub <= 16;
+    const double avg_bucket = (double)ix->n / (ix->sbits >= 32 ? 4294967296.0 : (double)(1ull << ix->sbits));
+    inblock = probes <= MQ_RADIUS_BUDGET && rsub <= 16 && (double)probes * avg_bucket <= MQ_ENTRY_BUDGET;
   }
   const uint32_t TQ = use_mih ? MIH_QTILE : 64u;
   uint32_t cap = std::max(wk->cap, use_mih ? std::max(ix->cap, 4096u) : 65536u);
