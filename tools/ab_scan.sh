@@ -9,9 +9,7 @@ run() {  # label, env...
     echo "$label n=$n  $r" | tee -a $OUT
   done
 }
-run "small nb2 w4          " VC_SCAN_SMALL=1
-run "small nb1 w8          " VC_SCAN_SHAPE=4,256,0
-run "small nb1 w6          " VC_SCAN_SHAPE=4,256,0 VERTICUT_GPU_LIB=$L/libverticut_gpu_w4.so
-run "general               " VC_SCAN_SMALL=0
-run "small nb2 w4 again    " VC_SCAN_SMALL=1
-run "small nb1 w8 again    " VC_SCAN_SHAPE=4,256,0
+for rep in 1 2 3; do
+run "small nb2 w4  rep$rep" VC_SCAN_SMALL=1
+run "small nb2 w3  rep$rep" VERTICUT_GPU_LIB=$L/libverticut_gpu_w3.so
+done

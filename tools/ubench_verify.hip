@@ -160,8 +160,8 @@ __global__ void __launch_bounds__(256, WPS) k2(const uint64_t* __restrict__ qg, 
       }
     }
     tau[q] = 3;
-    if (MODE != 1) tau[q] = __builtin_amdgcn_readfirstlane(tau[q] + (qg[0] == 1));
-    if (MODE == 1) asm volatile("" : "+v"(tau[q]));
+    if (MODE != 1 && MODE < 3) tau[q] = __builtin_amdgcn_readfirstlane(tau[q] + (qg[0] == 1));
+    if (MODE == 1 || MODE >= 3) asm volatile("" : "+v"(tau[q]));
   }
   if (MODE == 1) {
 #pragma unroll
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256, WPS) k2(const uint64_t* __restrict__ qg, 
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
       uint32_t w[2 * W];
-      if (MODE == 2) {
+      if (MODE >= 2) {
         const uint4 v = *reinterpret_cast<const uint4*>(&sq[q * W]);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
       } else {
@@ -187,6 +187,38 @@ __global__ void __launch_bounds__(256, WPS) k2(const uint64_t* __restrict__ qg, 
         for (int j = 0; j < 2 * W; ++j) w[j] = nq[q][j];
       }
       uint32_t orv = 0;
+      if (MODE >= 3) {   // runs: all xors of GRP item pairs first, then their popcounts (sched barriers keep hipcc from re-mixing)
+        constexpr int GRP = MODE == 3 ? 1 : (MODE == 4 ? 2 : 4);
+#pragma unroll
+        for (int u0 = 0; u0 < U; u0 += GRP) {
+          uint32_t x[GRP][W][4];
+#pragma unroll
+          for (int g = 0; g < GRP; ++g)
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              x[g][j][0] = (uint32_t)r[u0 + g][j].x ^ w[2 * j];
+              x[g][j][1] = (uint32_t)(r[u0 + g][j].x >> 32) ^ w[2 * j + 1];
+              x[g][j][2] = (uint32_t)r[u0 + g][j].y ^ w[2 * j];
+              x[g][j][3] = (uint32_t)(r[u0 + g][j].y >> 32) ^ w[2 * j + 1];
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < GRP; ++g) {
+            uint32_t da = tau[q], db = tau[q];
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              da = bcnt_acc(x[g][j][0], da);
+              db = bcnt_acc(x[g][j][2], db);
+              da = bcnt_acc(x[g][j][1], da);
+              db = bcnt_acc(x[g][j][3], db);
+            }
+            orv |= da | db;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (__ballot(orv >= 128u) != 0) hits += q + 1;
+        continue;
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         uint32_t da, db;
@@ -271,6 +303,9 @@ int main() {
   run2<0, 4>("U0 unrolled, SGPR queries", dq, dout, dcyc);
   run2<1, 4>("U1 unrolled, VGPR queries", dq, dout, dcyc);
   run2<2, 4>("U2 unrolled, LDS imm offsets", dq, dout, dcyc);
+  run2<3, 4>("U3 LDS imm, runs of 8 xor / 8 bcnt", dq, dout, dcyc);
+  run2<4, 4>("U4 LDS imm, runs of 16 / 16", dq, dout, dcyc);
+  run2<5, 4>("U5 LDS imm, runs of 32 / 32", dq, dout, dcyc);
   run2<0, 3>("U0 unrolled, SGPR, 3 waves/SIMD", dq, dout, dcyc);
   run2<1, 3>("U1 unrolled, VGPR, 3 waves/SIMD", dq, dout, dcyc);
   run2<0, 5>("U0 unrolled, SGPR, 5 waves/SIMD", dq, dout, dcyc);

@@ -91,6 +91,7 @@ static void read_knobs(VcKnobs* k) {
   if (const char* w = getenv("VC_SCAN_WRAP")) k->scan_wrap = (uint32_t)atoi(w);
   if (const char* w = getenv("VC_SCAN_DIAG")) k->scan_diag = (uint32_t)atoi(w);
   if (const char* s2 = getenv("VC_SAMPLE2")) { k->sample2_set = true; k->sample2 = strtoull(s2, nullptr, 10); }
+  if (const char* s1 = getenv("VC_SAMPLE1")) { k->sample1_set = true; k->sample1 = strtoull(s1, nullptr, 10); }
   if (const char* sh = getenv("VC_SCAN_SHAPE")) {
     int u = 0, b = 0, d = 2;
     if (sscanf(sh, "%d,%d,%d", &u, &b, &d) >= 1) { k->shape_set = true; k->shape_u = u; k->shape_blk = b; k->shape_db = d; }
@@ -587,18 +588,18 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
   LinearBufs b;
   int rc = linear_bufs(e, nq, k, &b);
   if (rc) return rc;
-  // Threshold bootstrap in two stages.  Stage 1: exact distance histogram of the first `sample` codes -> tau1 (k-th
-  // best of the sample).  Stage 2: histogram of an 8x larger prefix, counting only distances <= tau1 (rare, so it costs
-  // a plain scan of the prefix) -> tau2.  The tighter start keeps the verify kernel's first steps from flooding the
-  // ring / histogram atomics from every wave at once.  That flood cost ~0.4 ms per launch while eight queries shared
-  // one line for their ring cursors and one for their thresholds, and the optimum stage-2 sample was 8-16 M codes;
-  // with one line per query (VC_QUERY_LINE_WORDS) it costs 1-2 % without any stage 2 and the optimum is flat from
-  // 0.5 M to 4 M codes (profiles/r01_sweeps.md), so the sample is 2 M: 12 us instead of 30.
-  uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(262144, 64ull * k));
-  uint64_t sample2 = std::min<uint64_t>(e->n / 16, sample * 8);   // 2.1 M codes at k = 100
-  if (sample2 < 4 * sample) sample2 = 0;
+  // Threshold bootstrap: exact distance histogram of the first `sample` codes -> tau (k-th best of the sample), so that
+  // the verify kernel's first tiles do not flood the ring / histogram atomics from every wave at once (that flood cost
+  // ~0.4 ms per launch while eight queries shared one line for their ring cursors and one for their thresholds).
+  // Round 1 ran two stages (64 K codes exactly, then 2 M codes counting only distances <= tau1): 4 launches, 26 us.
+  // With one line per query the flood is mild and the threshold of ONE exact stage over 1.5 M codes starts the verify
+  // kernel just as well -- 2 launches, 18 us; a 125 M-code shard step 0.397 -> 0.384 ms, 1e9 unchanged
+  // (profiles/r02_sweeps.md).  The refining stage stays selectable (VC_SAMPLE2, tests).
+  uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(std::max<uint64_t>(262144, 64ull * k), std::min<uint64_t>(e->n / 16, 1572864)));
+  uint64_t sample2 = 0;
   if (e->knobs.sample2_set) sample2 = std::min<uint64_t>(e->n, e->knobs.sample2);   // dev/test knob VC_SAMPLE2
-  if (sample2) sample = std::min<uint64_t>(sample, std::max<uint64_t>(65536, 64ull * k));   // stage 1 only has to seed stage 2
+  if (e->knobs.sample1_set) sample = std::min<uint64_t>(e->n, e->knobs.sample1);      // dev/test knob VC_SAMPLE1
+  if (sample2 && !e->knobs.sample1_set) sample = std::min<uint64_t>(sample, std::max<uint64_t>(65536, 64ull * k));   // stage 1 only has to seed stage 2
   for (uint32_t g0 = 0; g0 < nq; g0 += b.GQ) {
     const uint32_t gq = std::min(b.GQ, nq - g0);
     const uint64_t* dg = d_q + (size_t)g0 * e->W;

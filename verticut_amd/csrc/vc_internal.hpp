@@ -7,6 +7,8 @@ struct VcKnobs {
   uint32_t scan_wrap = 0, scan_diag = 0;      // VC_SCAN_WRAP / VC_SCAN_DIAG (diagnostic build only; results wrong by design)
   bool sample2_set = false;                   // VC_SAMPLE2: size of the second bootstrap stage
   uint64_t sample2 = 0;
+  bool sample1_set = false;                   // VC_SAMPLE1: size of the first bootstrap stage
+  uint64_t sample1 = 0;
   bool shape_set = false;                     // VC_SCAN_SHAPE "U,BLK,DB"
   int shape_u = 0, shape_blk = 0, shape_db = 0;
   uint32_t sample_blocks_per_cu = 8;          // VC_SAMPLE_BLOCKS_PER_CU
