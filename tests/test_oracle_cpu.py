@@ -249,3 +249,29 @@ def test_wire_encoding_matches_proto2(tmp_path):
     assert got["binarycode"] == (b"\x0a" + _varint(16) + code).hex()
     assert got["imagelist"] == b"".join(b"\x0a" + _varint(len(pair(i))) + pair(i) for i in (0, 1000000, 2000000)).hex()
     assert got["roundtrip"] == "ok"
+
+
+def test_oracle_threaded_find_and_radius_search(oracle):
+    """round-2 oracle entry points (bench.py's CPU-MIH baselines): the m ranks of a radius iteration on m threads give
+    exactly the single-thread result (rank-order gather, mpi_coordinator.cc:34-69), and the fixed-radius neighbour
+    search (search_R_neighbors shells 0..r/m + gather + dedup, search_worker.cc:222-264) equals numpy brute force."""
+    import numpy as np
+    codes = oracle.gen_codes(30000, 64, 34, kind=1, n_centres=80, max_flips=6)
+    rng = np.random.default_rng(3)
+    for m, key_mode in ((2, 1), (4, 1), (4, 0)):
+        mo = oracle.MihOracle(codes, m, key_mode=key_mode)
+        for qi in rng.integers(0, len(codes), size=5):
+            q = codes[qi].copy()
+            q[int(rng.integers(0, 8))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+            a, sa = mo.find(q, 10, stop_mult=min(m, 4))
+            b, sb = mo.find(q, 10, stop_mult=min(m, 4), threads=m)
+            assert np.array_equal(a, b)
+            assert (sa.radius, sa.n_sub_reads, sa.n_sub_reads_all, sa.n_distinct) == (sb.radius, sb.n_sub_reads, sb.n_sub_reads_all, sb.n_distinct)
+            if key_mode == 1:                       # masked keys: MIH radius search is exact
+                for threads in (1, m):
+                    r, probes = mo.radius(q, 8, threads=threads)
+                    d = oracle.np_distances(codes, q)
+                    ids = np.nonzero(d <= 8)[0]
+                    assert np.array_equal(r, np.sort(oracle.pack(d[ids], ids.astype(np.uint64))))
+                    import math
+                    assert probes == m * sum(math.comb(64 // m, j) for j in range(8 // m + 1))
