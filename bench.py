@@ -247,10 +247,23 @@ def measure_traffic(args, kernel_substr):
             env = dict(os.environ, TMPDIR="/tmp")
             cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td, "--",
                    sys.executable, os.path.join(ROOT, "bench.py")] + base
+            # the child gets its own process group so that a hung profiler run can be ended as a whole (exact pgid)
             try:
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
-            except Exception as ex:   # noqa: BLE001 -- any failure means "not measured"
-                return None, "rocprofv3 --pmc %s child run failed: %s" % (counter, type(ex).__name__)
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            except OSError as ex:
+                return None, "rocprofv3 could not be started: %s" % ex
+            try:
+                rc = proc.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                return None, "rocprofv3 --pmc %s child run timed out" % counter
+            if rc != 0:
+                return None, "rocprofv3 --pmc %s child run failed (exit %d)" % (counter, rc)
             got = []
             for f in glob.glob(os.path.join(td, "**", "*_counter_collection.csv"), recursive=True):
                 with open(f) as fh:

@@ -384,3 +384,46 @@ def test_radius_search_with_huge_neighbourhoods(vc, oracle, bits, m):
             assert np.array_equal(mih[i], exp), i
             assert np.array_equal(lin[i], exp), i
         assert max(len(r) for r in mih) > 20000 and min(len(r) for r in mih) < 10
+
+
+@pytest.mark.parametrize("bits,m", [(512, 16), (512, 64), (256, 8)])
+def test_wide_codes_many_tables(vc, oracle, bits, m):
+    """512-bit codes: 16 tables of 32-bit substrings (16 occupancy bitmaps, 16 mask sets in the query kernel's LDS) and 64
+    tables of 8-bit substrings; exact k-NN statistics against the oracle, radius search against numpy."""
+    n, k = 20000, 10
+    rng = np.random.default_rng(bits + m)
+    codes = oracle.gen_codes(n, bits, 5, kind=1, n_centres=100, max_flips=3 * m // 4 + 2)
+    q = _near_queries(codes, 6, rng, 3)
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        e.build_index()
+        got, cnt, st = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        for i in range(len(q)):
+            ores, ost = mo.find(q[i], k, stop_mult=4)
+            _check_contract(got[i, : cnt[i]], ores)
+            assert (st[i].radius, st[i].n_sub_reads, st[i].n_candidates) == (ost.radius, ost.n_sub_reads, ost.n_distinct)
+        radius = m                                          # substring shells 0..1
+        rad = e.search_radius(q[:3], radius, mode=vc.MODE_MIH_EXACT)
+        for i in range(3):
+            d = oracle.np_distances(codes, q[i])
+            ids = np.nonzero(d <= radius)[0]
+            assert np.array_equal(rad[i], np.sort(oracle.pack(d[ids], ids.astype(np.uint64))))
+
+
+def test_radius_larger_than_the_probe_budget_falls_back_to_the_scan(vc, oracle):
+    """a radius whose substring shells would enumerate more keys than the shard has items (here: every key of a 32-bit
+    substring) is answered by the scan: same rows as numpy, in finite time"""
+    n, bits, m = 5000, 128, 4
+    codes = oracle.gen_codes(n, bits, 8)
+    q = codes[:2].copy()
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        e.build_index()
+        for radius in (60, 128):
+            rad = e.search_radius(q, radius, mode=vc.MODE_MIH_EXACT, cap_per_query=8192)
+            for i in range(2):
+                d = oracle.np_distances(codes, q[i])
+                ids = np.nonzero(d <= radius)[0]
+                assert np.array_equal(rad[i], np.sort(oracle.pack(d[ids], ids.astype(np.uint64))))
+        assert len(rad[0]) == n                              # radius = bits: everything

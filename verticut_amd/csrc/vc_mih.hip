@@ -1882,6 +1882,14 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
     if (err) *err = "index is stale: codes were added after vc_build_index()";
     return VC_ERR_STATE;
   }
+  if (use_mih) {
+    // a radius whose substring shells cost more probes than scanning the shard costs distance evaluations is answered
+    // by the scan (identical results; search_R_neighbors would enumerate up to 2^s keys per table, search_worker.cc:222-264)
+    const uint32_t rsub = std::min(ix->sbits, std::min(radius, W * 64) / ix->m);
+    double probes = 0;
+    for (uint32_t r = 0; r <= rsub; ++r) probes += (double)ix->m * binom_host(ix->sbits, r);
+    if (probes > (double)std::max<uint64_t>(n, 1u << 20)) use_mih = false;
+  }
   const uint32_t TQ = use_mih ? MIH_QTILE : 64u;
   if (wk->tq != TQ) {   // tile shape changed (scan <-> MIH): start over with fresh buffers
     vc_radius_work_free(wk);
