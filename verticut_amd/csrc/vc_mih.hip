@@ -734,54 +734,67 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
     __syncthreads();
   };
 
-  // ---- one table of one shell, 32-bit substrings: granule scan over the segments in s_seg*
-  auto scan32 = [&](uint32_t t) {
-    const VcTableView& tv = s_tv[t];
-    const uint32_t qk = qkey(t), qhi = qk >> 7, qlo = qk & 127u;
-    const uint32_t total = s_segstart[s_nseg];
+  // ---- one shell (or the whole ball) of ALL tables, 32-bit substrings: granule scan over the segments in s_seg*.
+  // The tables share one item space (item = table * per_table + pattern index), so the 1-, 26- and 326-granule shells
+  // 0..2 of four tables are 1 + 1 + 2 passes, not 4 + 4 + 4: a pass costs a barrier and a memory round trip whatever it holds.
+  auto scan32 = [&]() {
+    const uint32_t per_table = s_segstart[s_nseg];
+    const uint32_t total = per_table * m;
     for (uint32_t base = 0; base < total; base += MQ_PASS) {
       const uint32_t idx0 = base + tid * MQ_G;
-      uint32_t seg = 0, hi = 0;
+      uint32_t t = 0, rem = 0, seg = 0, hi = 0;
       if (idx0 < total) {
-        while (idx0 >= s_segstart[seg + 1]) ++seg;
-        hi = mq_unrank(s_binom, idx0 - s_segstart[seg], s_segh[seg], 25);
+        t = idx0 / per_table;
+        rem = idx0 - t * per_table;
+        while (rem >= s_segstart[seg + 1]) ++seg;
+        hi = mq_unrank(s_binom, rem - s_segstart[seg], s_segh[seg], 25);
       }
       uint4 v[MQ_G];
-      uint32_t gr[MQ_G], hh[MQ_G], mi[MQ_G];
+      uint32_t gr[MQ_G], meta0[MQ_G], mi[MQ_G], qlo[MQ_G];   // meta0 = table | |hi| << 8
 #pragma unroll
       for (uint32_t g = 0; g < MQ_G; ++g) {
         const uint32_t idx = idx0 + g;
-        gr[g] = 0; hh[g] = 0; mi[g] = 0;
+        gr[g] = 0; meta0[g] = 0; mi[g] = 0; qlo[g] = 0;
         v[g] = make_uint4(0, 0, 0, 0);
         if (idx < total) {
           if (g) {
-            if (idx == s_segstart[seg + 1]) {
+            ++rem;
+            if (rem == per_table) {                 // next table: its first pattern
+              ++t;
+              rem = 0;
+              seg = 0;
+              hi = (1u << s_segh[0]) - 1u;
+            } else if (rem == s_segstart[seg + 1]) {
               ++seg;
               hi = (1u << s_segh[seg]) - 1u;
             } else {
               hi = vc_next_comb(hi);
             }
           }
-          gr[g] = qhi ^ hi;
-          hh[g] = s_segh[seg];
-          mi[g] = s_segmask[seg];
-          v[g] = *reinterpret_cast<const uint4*>(tv.bitmap + ((uint64_t)gr[g] << 2));
+          const uint32_t qk = qkey(t);
+          gr[g] = (qk >> 7) ^ hi;
+          qlo[g] = qk & 127u;
+          meta0[g] = t | (s_segh[seg] << 8);
+          mi[g] = t * 8 + s_segmask[seg];
+          v[g] = *reinterpret_cast<const uint4*>(s_tv[t].bitmap + ((uint64_t)gr[g] << 2));
         }
       }
       uint32_t w[MQ_G][4];
-      uint32_t cnt = 0;
+      uint32_t cnt = 0, cnt0 = 0;
 #pragma unroll
       for (uint32_t g = 0; g < MQ_G; ++g) {
-        const uint32_t* mk = s_mask + (t * 8 + mi[g]) * 4;
+        const uint32_t* mk = s_mask + mi[g] * 4;
         w[g][0] = v[g].x & mk[0];
         w[g][1] = v[g].y & mk[1];
         w[g][2] = v[g].z & mk[2];
         w[g][3] = v[g].w & mk[3];
-        cnt += __popc(w[g][0]) + __popc(w[g][1]) + __popc(w[g][2]) + __popc(w[g][3]);
+        const uint32_t c = __popc(w[g][0]) + __popc(w[g][1]) + __popc(w[g][2]) + __popc(w[g][3]);
+        cnt += c;
+        if ((meta0[g] & 0xFFu) == 0 && idx0 + g < per_table) cnt0 += c;
       }
-      if (t == 0 && (p.flags & VC_FLAG_USE_BITMAP)) {   // n_sub_reads_ = leaves whose bit is set (search_worker.cc:238-245)
+      if (p.flags & VC_FLAG_USE_BITMAP) {   // n_sub_reads_ of table 0 = its leaves whose bit is set (search_worker.cc:238-245)
         uint32_t wt;
-        (void)vc_wave_excl_scan(cnt, wt);
+        (void)vc_wave_excl_scan(cnt0, wt);
         if (lane == 0 && wt) atomicAdd(&s_hits0, wt);
       }
       for (;;) {   // append this pass's hits; what does not fit waits for a drain
@@ -796,11 +809,11 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
 #pragma unroll
           for (uint32_t i = 0; i < 4; ++i)
             while (w[g][i] && pos < MQ_HMAX) {
-              const uint32_t b = (uint32_t)__ffs((int)w[g][i]) - 1u;
+              const uint32_t bb = (uint32_t)__ffs((int)w[g][i]) - 1u;
               w[g][i] &= w[g][i] - 1u;
-              const uint32_t x = i * 32 + b;
+              const uint32_t x = i * 32 + bb;
               s_key[pos] = (gr[g] << 7) | x;
-              s_meta[pos] = t | ((hh[g] + __popc(x ^ qlo)) << 8);
+              s_meta[pos] = meta0[g] + (__popc(x ^ qlo[g]) << 8);
               ++pos;
               --cnt;
             }
@@ -812,36 +825,52 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
     }
   };
 
-  // ---- one table of one shell, <= 16-bit substrings: direct offsets, keys by combination unranking + Gosper
-  auto scan_direct = [&](uint32_t t, uint32_t r) {
-    const VcTableView& tv = s_tv[t];
-    const uint32_t qk = qkey(t);
+  // ---- one shell of ALL tables, <= 16-bit substrings: direct offsets, keys by combination unranking + Gosper
+  auto scan_direct = [&](uint32_t r) {
     const uint32_t nkeys = s_binom[s * MQ_BW + r];
-    for (uint32_t base = 0; base < nkeys; base += MQ_PASS) {
+    const uint32_t total = nkeys * m;
+    for (uint32_t base = 0; base < total; base += MQ_PASS) {
       const uint32_t j0 = base + tid * MQ_G;
-      uint32_t mask = j0 < nkeys ? mq_unrank(s_binom, j0, r, s) : 0u;
-      uint32_t offv[MQ_G], lenv[MQ_G];
-      uint32_t cnt = 0;
+      uint32_t t = 0, rem = 0, mask = 0;
+      if (j0 < total) {
+        t = j0 / nkeys;
+        rem = j0 - t * nkeys;
+        mask = mq_unrank(s_binom, rem, r, s);
+      }
+      uint32_t offv[MQ_G], lenv[MQ_G], tt[MQ_G];
+      uint32_t cnt = 0, cnt0 = 0;
 #pragma unroll
       for (uint32_t g = 0; g < MQ_G; ++g) {
         offv[g] = 0;
         lenv[g] = 0;
-        if (j0 + g < nkeys) {
-          if (g) mask = vc_next_comb(mask);
+        tt[g] = 0;
+        if (j0 + g < total) {
+          if (g) {
+            ++rem;
+            if (rem == nkeys) {                     // next table: its first key of the shell
+              ++t;
+              rem = 0;
+              mask = r ? (1u << r) - 1u : 0u;
+            } else {
+              mask = vc_next_comb(mask);
+            }
+          }
+          tt[g] = t;
           // binaryToInt's sign-extended keys (Pilaf/image_tools.h:13): a probe that flips the top bit matches nothing
           const bool dead = (p.flags & VC_FLAG_REF_SIGNEXT_KEYS) && ((mask >> (s - 1)) & 1u);
           if (!dead) {
-            const uint32_t key = qk ^ mask;
-            const uint32_t a = tv.offsets[key], b = tv.offsets[key + 1];
-            offv[g] = a;
-            lenv[g] = b - a;
+            const uint32_t key = qkey(t) ^ mask;
+            const uint32_t a0 = s_tv[t].offsets[key], b0 = s_tv[t].offsets[key + 1];
+            offv[g] = a0;
+            lenv[g] = b0 - a0;
           }
           cnt += lenv[g] != 0;
+          if (t == 0) cnt0 += lenv[g] != 0;
         }
       }
-      if (t == 0 && (p.flags & VC_FLAG_USE_BITMAP)) {
+      if (p.flags & VC_FLAG_USE_BITMAP) {
         uint32_t wt;
-        (void)vc_wave_excl_scan(cnt, wt);
+        (void)vc_wave_excl_scan(cnt0, wt);
         if (lane == 0 && wt) atomicAdd(&s_hits0, wt);
       }
       for (;;) {
@@ -856,7 +885,7 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
           if (lenv[g] && pos < MQ_HMAX) {
             s_key[pos] = offv[g];
             s_pref[pos] = lenv[g];
-            s_meta[pos] = t | (r << 8);
+            s_meta[pos] = tt[g] | (r << 8);
             lenv[g] = 0;
             ++pos;
             --cnt;
@@ -894,10 +923,9 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
     // fixed-radius neighbour search: shells 0 .. r_last of every table, every item within the full distance kept
     if (s == 32) {
       plan32(p.r_last, true);
-      for (uint32_t t = 0; t < m; ++t) scan32(t);
+      scan32();
     } else {
-      for (uint32_t r = 0; r <= p.r_last; ++r)
-        for (uint32_t t = 0; t < m; ++t) scan_direct(t, r);
+      for (uint32_t r = 0; r <= p.r_last; ++r) scan_direct(r);
     }
     if (s_nh) drain();
     __syncthreads();
@@ -924,9 +952,9 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
   for (uint32_t r = 0; r <= p.r_last; ++r) {
     if (s == 32) {
       plan32(r, false);
-      for (uint32_t t = 0; t < m; ++t) scan32(t);
+      scan32();
     } else {
-      for (uint32_t t = 0; t < m; ++t) scan_direct(t, r);
+      scan_direct(r);
     }
     if (s_nh) drain();
     __syncthreads();
