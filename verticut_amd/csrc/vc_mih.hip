@@ -31,7 +31,8 @@
 #define MIH_PPT 4                       // probes per thread
 #define MIH_EPT 4u                      // bucket entries per thread and round in the verify phase
 #define MIH_PCH (MIH_BLK * MIH_PPT)     // probes per block pass
-#define MIH_QTILE 1024u                 // queries resident per search tile (one block each in mih_query_kernel)
+#define MIH_QTILE 4096u                 // queries resident per search tile (one block each in mih_query_kernel)
+#define MIH_RADIUS_TILE 1024u            // queries per tile of the radius search (vc_radius_offsets_kernel: one thread each)
 #define MIH_APPROX_FACTOR 20u           // search_worker.h:14
 
 struct VcTableView {
@@ -420,6 +421,13 @@ __global__ void __launch_bounds__(VC_WAVE) mih_commit_kernel(const CommitParams 
   }
 }
 
+// queries handed over by mih_query_kernel: committed top-k (st.topk) -> front of the slot's candidate ring
+__global__ void __launch_bounds__(256) mih_seed_ring_kernel(MihState st, const uint32_t* __restrict__ list, uint32_t k, uint32_t cap) {
+  const uint32_t slot = list[blockIdx.x];
+  const uint32_t kk = st.count[slot];
+  for (uint32_t i = threadIdx.x; i < kk; i += blockDim.x) st.ring[(uint64_t)slot * cap + i] = st.topk[(uint64_t)slot * k + i];
+}
+
 __global__ void __launch_bounds__(256) mih_init_kernel(MihState st, uint32_t nq, uint32_t* list, uint64_t thresh0) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
@@ -580,7 +588,7 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
   uint32_t ring_fill = 0;          // radius mode: entries already in the global ring       (block-uniform)
   unsigned long long sub = 0, loc = 0;   // get_stat counters of table 0 (block-uniform)
   unsigned long long w_probes = 0, w_hits = 0, w_entries = 0;   // algorithmic work of this query (block-uniform)
-  uint64_t* const ring = p.st.ring + (uint64_t)slot * p.cap;
+  uint64_t* const ring = p.st.ring + (uint64_t)slot * p.cap;   // radius mode only (k-NN hand-over goes through st.topk)
   auto put_work = [&]() {
     if (tid == 0) {
       p.st.work[slot * 4 + 0] = w_probes;
@@ -993,7 +1001,7 @@ __global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelPara
   }
   // not finished: hand the query to the multi-block shells (state exactly as mih_commit_kernel leaves it)
   put_work();
-  for (uint32_t i = tid; i < kk; i += MQ_BLK) ring[i] = s_buf[i];
+  for (uint32_t i = tid; i < kk; i += MQ_BLK) p.st.topk[(uint64_t)slot * p.k + i] = s_buf[i];   // mih_seed_ring_kernel moves it into the ring
   if (tid == 0) {
     p.st.count[slot] = kk;
     p.st.prev[slot] = kk;
@@ -1114,6 +1122,8 @@ struct VcMihIndex {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   unsigned long long* d_totals = nullptr;   // probes | non-empty buckets | entries verified | queries
+  uint64_t* d_ring = nullptr;               // [MIH_QTILE][cap] candidate rings of the multi-block shells (lazy)
+  size_t ring_entries = 0;
 };
 
 #define MIH_CHECK(call)                                                                                  \
@@ -1150,6 +1160,7 @@ void vc_mih_free(VcMihIndex* ix) {
   if (ix->h_ctr) (void)hipHostFree(ix->h_ctr);
   for (auto& pr : ix->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   (void)hipFree(ix->d_totals);
+  (void)hipFree(ix->d_ring);
   delete ix;
 }
 
@@ -1511,11 +1522,13 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
 }
 
 // ---- search -------------------------------------------------------------------------------------------
-static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, MihState* st, std::string* err) {
+// per-slot state of a search tile.  The candidate rings ([slot][cap], 2 GB at the default cap) are used only by the
+// multi-block shells and are allocated the first time a query gets there (with_ring).
+static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, bool with_ring, MihState* st, std::string* err) {
   const size_t Q = MIH_QTILE;
   size_t bytes = 0;
   auto take = [&](size_t b) { size_t o = bytes; bytes += (b + 255) & ~(size_t)255; return o; };
-  const size_t o_thresh = take(Q * 8), o_ring = take(Q * cap * 8), o_count = take(Q * 4), o_prev = take(Q * 4),
+  const size_t o_thresh = take(Q * 8), o_count = take(Q * 4), o_prev = take(Q * 4),
                o_seen = take(Q * 8), o_sub = take(Q * 8), o_loc = take(Q * 8), o_radius = take(Q * 4),
                o_topk = take(Q * (size_t)k * 8), o_topn = take(Q * 4), o_work = take(Q * 4 * 8);
   if (bytes > ix->tile_bytes) {
@@ -1525,10 +1538,17 @@ static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, MihState* st, s
     MIH_CHECK(hipMalloc(&ix->d_tile, bytes));
     ix->tile_bytes = bytes;
   }
+  if (with_ring && ix->ring_entries < Q * cap) {
+    if (ix->d_ring) MIH_CHECK(hipFree(ix->d_ring));
+    ix->d_ring = nullptr;
+    ix->ring_entries = 0;
+    MIH_CHECK(hipMalloc((void**)&ix->d_ring, Q * cap * 8));
+    ix->ring_entries = Q * cap;
+  }
   if (!ix->d_lists) MIH_CHECK(hipMalloc((void**)&ix->d_lists, (4 * Q + 4) * 4));
   uint8_t* b = (uint8_t*)ix->d_tile;
   st->thresh = (uint64_t*)(b + o_thresh);
-  st->ring = (uint64_t*)(b + o_ring);
+  st->ring = ix->d_ring;
   st->count = (uint32_t*)(b + o_count);
   st->prev = (uint32_t*)(b + o_prev);
   st->seen = (unsigned long long*)(b + o_seen);
@@ -1656,9 +1676,6 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   // stop multiplier: the reference's literal 4 (search_worker.cc:204); min(m,4) keeps m < 4 exact
   const uint32_t stop_mult = (ix->flags & VC_FLAG_REF_STOP_LITERAL4) ? 4u : std::min(ix->m, 4u);
   MihState st;
-  if ((rc = ensure_tile(ix, k, cap, &st, err))) return rc;
-  uint32_t* lists[4] = {ix->d_lists, ix->d_lists + MIH_QTILE, ix->d_lists + 2 * MIH_QTILE, ix->d_lists + 3 * MIH_QTILE};
-  uint32_t* d_ctr = ix->d_lists + 4 * MIH_QTILE;
   if (!ix->h_ctr) MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 16, hipHostMallocDefault));   // pageable memory makes the read-back a staged copy
   uint32_t* h_ctr = ix->h_ctr;
 
@@ -1667,6 +1684,9 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   uint32_t buf_entries = 1024;
   while (buf_entries < k + MQ_ROUND) buf_entries <<= 1;
   const bool inblock = ix->knobs.mih_host_loop == 0 && buf_entries <= 8192 && ix->m <= 64;
+  if ((rc = ensure_tile(ix, k, cap, !inblock, &st, err))) return rc;
+  uint32_t* lists[4] = {ix->d_lists, ix->d_lists + MIH_QTILE, ix->d_lists + 2 * MIH_QTILE, ix->d_lists + 3 * MIH_QTILE};
+  uint32_t* d_ctr = ix->d_lists + 4 * MIH_QTILE;
   const double avg_bucket = (double)ix->n / (S >= 32 ? 4294967296.0 : (double)(1ull << S));
   const uint32_t r_last = inblock_last_shell(S, ix->m, MQ_KNN_BUDGET, S, avg_bucket);
   const bool trace = ix->knobs.mih_trace;   // VC_MIH_TRACE: per-shell wall times on stderr
@@ -1692,7 +1712,12 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       if (trace)
         fprintf(stderr, "[vc_mih] shells 0..%u in one launch: %u queries, %u continue  %.1f us\n", r_last, qt, n_cur,
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_q).count());
-      if (n_heavy) MIH_CHECK(hipMemcpyAsync(lists[3], cur, (size_t)n_heavy * 4, hipMemcpyDeviceToDevice, s));
+      if (n_heavy) {
+        MIH_CHECK(hipMemcpyAsync(lists[3], cur, (size_t)n_heavy * 4, hipMemcpyDeviceToDevice, s));
+        if ((rc = ensure_tile(ix, k, cap, true, &st, err))) return rc;   // the rings exist from the first hand-over on
+        hipLaunchKernelGGL(mih_seed_ring_kernel, dim3(n_heavy), dim3(256), 0, s, st, (const uint32_t*)cur, k, cap);
+        MIH_CHECK(hipGetLastError());
+      }
     } else {
       hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, cur, (uint64_t)VC_PACK_INF);
       MIH_CHECK(hipGetLastError());
@@ -1796,7 +1821,7 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
     const double avg_bucket = (double)ix->n / (ix->sbits >= 32 ? 4294967296.0 : (double)(1ull << ix->sbits));
     inblock = probes <= MQ_RADIUS_BUDGET && rsub <= 16 && (double)probes * avg_bucket <= MQ_ENTRY_BUDGET;
   }
-  const uint32_t TQ = use_mih ? MIH_QTILE : 64u;
+  const uint32_t TQ = use_mih ? MIH_RADIUS_TILE : 64u;
   uint32_t cap = std::max(wk->cap, use_mih ? std::max(ix->cap, 4096u) : 65536u);
   while (cap & (cap - 1)) cap += cap & (0u - cap);   // power of two: the in-place segment sort pads to one
 #define R_CHECK(call)                                                      \
@@ -1836,7 +1861,7 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
       const uint32_t qt = std::min(TQ, nq - q0);
       const uint32_t* sorted_flag = nullptr;
       if (use_mih) {
-        if ((rc = ensure_tile(ix, 1, 1, &st, err))) return rc;
+        if ((rc = ensure_tile(ix, 1, 1, false, &st, err))) return rc;
         st.ring = wk->d_ring;   // radius search keeps every neighbour: the big ring instead of the tile's
         st.count = d_count;
         st.topn = d_sorted;
@@ -1918,7 +1943,7 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
     for (uint32_t r = 0; r <= rsub; ++r) probes += (double)ix->m * binom_host(ix->sbits, r);
     if (probes > (double)std::max<uint64_t>(n, 1u << 20)) use_mih = false;
   }
-  const uint32_t TQ = use_mih ? MIH_QTILE : 64u;
+  const uint32_t TQ = use_mih ? MIH_RADIUS_TILE : 64u;
   if (wk->tq != TQ) {   // tile shape changed (scan <-> MIH): start over with fresh buffers
     vc_radius_work_free(wk);
     wk->tq = TQ;
