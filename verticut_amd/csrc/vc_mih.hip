@@ -32,7 +32,7 @@
 #define MIH_EPT 4u                      // bucket entries per thread and round in the verify phase
 #define MIH_PCH (MIH_BLK * MIH_PPT)     // probes per block pass
 #define MIH_QTILE 4096u                 // queries resident per search tile (one block each in mih_query_kernel)
-#define MIH_RADIUS_TILE 1024u            // queries per tile of the radius search (vc_radius_offsets_kernel: one thread each)
+#define MIH_RADIUS_TILE 4096u            // queries per tile of the radius search (vc_radius_offsets_kernel: four per thread)
 #define MIH_APPROX_FACTOR 20u           // search_worker.h:14
 
 struct VcTableView {
@@ -1069,18 +1069,32 @@ __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t*
   const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
   if (threadIdx.x == 0) s_max = 0;
   __syncthreads();
-  const uint32_t c = threadIdx.x < nq ? count[threadIdx.x] : 0u;
+  constexpr uint32_t PER = MIH_RADIUS_TILE / 1024;   // consecutive queries per thread
+  uint32_t c[PER], mine = 0, mx = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < PER; ++i) {
+    const uint32_t q = threadIdx.x * PER + i;
+    c[i] = q < nq ? count[q] : 0u;
+    mine += c[i];                                     // (cap <= 2^26: a wave's 64 x PER counts stay below 2^32)
+    mx = max(mx, c[i]);
+  }
   uint32_t wtot;
-  const uint32_t ex = vc_wave_excl_scan(c, wtot);   // a wave's 64 counts stay far below 2^32 (cap <= 2^26)
+  uint32_t ex = vc_wave_excl_scan(mine, wtot);
   if (lane == 0) s_w[wave] = wtot;
-  atomicMax(&s_max, c);
+  atomicMax(&s_max, mx);
   __syncthreads();
   uint64_t base = tot[0], total = 0;
   for (uint32_t w = 0; w < 1024 / VC_WAVE; ++w) {
     if (w < wave) base += s_w[w];
     total += s_w[w];
   }
-  if (threadIdx.x < nq) offsets[threadIdx.x] = base + ex;
+  uint64_t run = base + ex;
+#pragma unroll
+  for (uint32_t i = 0; i < PER; ++i) {
+    const uint32_t q = threadIdx.x * PER + i;
+    if (q < nq) offsets[q] = run;
+    run += c[i];
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     offsets[nq] = tot[0] + total;
