@@ -15,11 +15,16 @@ for i in range(200):
     for b in rng.choice(bits, size=int(rng.integers(0, 5)), replace=False):
         c[b // 8] ^= np.uint8(1 << (b % 8))
     qs.append(c[None, :].copy())
+allq = np.concatenate(qs)
 for mode, name in ((vc.MODE_MIH_EXACT, "mih_exact"), (vc.MODE_MIH_APPROX, "mih_approx"), (vc.MODE_LINEAR, "linear")):
-    for q in qs[:5]:
-        e.search_knn(q, k, mode=mode, with_stats=True)
-    t0 = time.perf_counter()
-    for q in qs:
-        e.search_knn(q, k, mode=mode, with_stats=True)
-    dt = time.perf_counter() - t0
-    print("%s: %.1f us per single-query call (%d queries, host API incl. PCIe and statistics)" % (name, dt / len(qs) * 1e6, len(qs)), flush=True)
+    for nq in (1, 16, 128):
+        if mode == vc.MODE_LINEAR and nq > 1:
+            continue
+        batches = [allq[i:i + nq] for i in range(0, len(allq) - nq + 1, nq)][:200]
+        for q in batches[:3]:
+            e.search_knn(q, k, mode=mode, with_stats=True)
+        t0 = time.perf_counter()
+        for q in batches:
+            e.search_knn(q, k, mode=mode, with_stats=True)
+        dt = time.perf_counter() - t0
+        print("%s nq=%d: %.1f us per call (%d calls, host API incl. PCIe and statistics)" % (name, nq, dt / len(batches) * 1e6, len(batches)), flush=True)

@@ -1702,7 +1702,13 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   uint32_t* lists[4] = {ix->d_lists, ix->d_lists + MIH_QTILE, ix->d_lists + 2 * MIH_QTILE, ix->d_lists + 3 * MIH_QTILE};
   uint32_t* d_ctr = ix->d_lists + 4 * MIH_QTILE;
   const double avg_bucket = (double)ix->n / (S >= 32 ? 4294967296.0 : (double)(1ull << S));
-  const uint32_t r_last = inblock_last_shell(S, ix->m, MQ_KNN_BUDGET, S, avg_bucket);
+  // One block per query: a small batch leaves most of the chip idle while a few blocks walk a big shell, so the probe
+  // budget per query shrinks with the batch (a lone query runs shells 0..2 in its block -- 2 116 probes at m = 4 -- and
+  // the bigger ones through the multi-block kernels, which spread a shell over all CUs).
+  uint64_t knn_budget = MQ_KNN_BUDGET;
+  if (nq < 1024) knn_budget = std::max<uint64_t>(2500, MQ_KNN_BUDGET * nq / 1024);
+  if (ix->knobs.mih_budget) knn_budget = ix->knobs.mih_budget;   // dev knob VC_MIH_BUDGET
+  const uint32_t r_last = inblock_last_shell(S, ix->m, knn_budget, S, avg_bucket);
   const bool trace = ix->knobs.mih_trace;   // VC_MIH_TRACE: per-shell wall times on stderr
 
   for (uint32_t q0 = 0; q0 < nq; q0 += MIH_QTILE) {
