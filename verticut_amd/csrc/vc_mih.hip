@@ -483,8 +483,13 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 #define MQ_BLK 256u
 #define MQ_G 4u                         // granules / keys per thread per pass
 #define MQ_PASS (MQ_BLK * MQ_G)
+#ifndef MQ_HMAX
 #define MQ_HMAX 1024u                   // LDS hit list (non-empty buckets awaiting a drain)
-#define MQ_HFLUSH 512u
+#endif
+#define MQ_HFLUSH (MQ_HMAX / 2)
+#ifndef MQ_MINW
+#define MQ_MINW 4
+#endif
 #define MQ_ROUND (MQ_BLK * MIH_EPT)     // bucket entries verified per round
 #define MQ_BW 17u                       // row width of the LDS binomial table: C(c, i), c <= 32, i <= 16
 #define MQ_MODE_EXACT 0u
@@ -520,7 +525,7 @@ __device__ __forceinline__ uint32_t mq_unrank(const uint32_t* sb, uint32_t j, ui
 }
 
 template <int W>
-__global__ void __launch_bounds__(MQ_BLK) mih_query_kernel(const QueryKernelParams p) {
+__global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kernel(const QueryKernelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* s_buf = (uint64_t*)smem;                         // [buf_entries] top-k (sorted) | fresh candidates
   uint32_t* s_key = (uint32_t*)(s_buf + p.buf_entries);      // [MQ_HMAX] bucket key, then bucket offset
