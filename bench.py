@@ -231,7 +231,7 @@ def timed_steps(env, run_steps, steps):
     return res, env.max_over_ranks(t1 - t0)
 
 
-def measure_traffic(args, kernel_substr):
+def measure_traffic(args, kernel_substr, fetch_mult=2.0, extra=()):
     """roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters of a short child run of this
     same script under rocprofv3 (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, TCC slots; FETCH_SIZE x 2 for a
     wide coalesced stream on gfx950 -- MI355X_MICROARCH.md, HBM section).  None when rocprofv3 is unavailable or fails."""
@@ -243,7 +243,7 @@ def measure_traffic(args, kernel_substr):
     vals = {}
     base = ["--workload", args.workload, "--db-size", repr(float(args.n)), "--bits", str(args.bits), "--k", str(args.k),
             "--queries", str(args.queries), "--seed", str(args.seed), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
-            "--no-check", "--no-traffic"]
+            "--no-check", "--no-traffic"] + list(extra)
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
             env = dict(os.environ, TMPDIR="/tmp")
@@ -275,8 +275,8 @@ def measure_traffic(args, kernel_substr):
             if not got:
                 return None, "no %s rows for %s" % (counter, kernel_substr)
             vals[counter] = sum(got[1:]) / max(len(got) - 1, 1) if len(got) > 1 else got[0]   # drop the first (cold) launch
-    return (vals["FETCH_SIZE"] * 2 + vals["WRITE_SIZE"]) * 1024.0, \
-        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB) of a 3-step child run: FETCH_SIZE x 2 + WRITE_SIZE"
+    return (vals["FETCH_SIZE"] * fetch_mult + vals["WRITE_SIZE"]) * 1024.0, \
+        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB) of a 3-step child run: FETCH_SIZE x %g + WRITE_SIZE" % fetch_mult
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -522,6 +522,10 @@ def run_c2(args, env, emit):
         "roofline": lines[m0]["roofline"],
         "results_check": "ok" if ok else "FAILED",
     }
+    if not args.no_traffic and line["roofline"].get("achieved") is not None:
+        # memory-side requests of the query kernel (64 bytes each); the x2 of a wide stream does not apply to 16-byte gathers
+        t, how = measure_traffic(args, "mih_query_kernel", fetch_mult=1.0, extra=("--tables", str(m0)))
+        line["roofline"]["traffic"], line["roofline"]["traffic_how"] = t, how + " (64-byte requests of 16-byte granule loads and gathers; uncorrected)"
     if args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline_mih(args, m0, "radius", radius=radius)
     emit(line)
@@ -571,6 +575,9 @@ def run_knn_mih(args, env, emit):
         "roofline": _mih_roofline(tm, bits),
         "results_check": "ok" if ok else "FAILED",
     }
+    if not args.no_traffic:
+        t, how = measure_traffic(args, "mih_query_kernel", fetch_mult=1.0)
+        line["roofline"]["traffic"], line["roofline"]["traffic_how"] = t, how + " (64-byte requests of 16-byte granule loads and gathers; uncorrected)"
     if args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline_mih(args, m, "knn", clustered=True)
     emit(line)

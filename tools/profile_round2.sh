@@ -23,11 +23,11 @@ step pmc c3 sq; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_W
 for w in c2 knn_mih c5shard; do
   step bench $w; (cd $R && python bench.py --workload $w --cpu-seconds 8 > $OUT/bench_$w.json 2> $OUT/bench_$w.err) || { tail -20 $OUT/bench_$w.err; exit 1; }
   cat $OUT/bench_$w.json
-  step stats $w; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- python3 $R/bench.py --workload $w --cpu-seconds 0 --no-check > $OUT/stats_$w.log 2>&1 || { tail -5 $OUT/stats_$w.log; exit 1; }
+  step stats $w; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- python3 $R/bench.py --workload $w --cpu-seconds 0 --no-check --no-traffic > $OUT/stats_$w.log 2>&1 || { tail -5 $OUT/stats_$w.log; exit 1; }
 done
 for w in c2 knn_mih; do   # (c2: the m = 2 engine only, so that the per-launch averages are of one kernel shape)
-  step pmc $w fetch; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_${w}_fetch -- python3 $R/bench.py --workload $w --tables 2 --steps 4 --warmup 2 --cpu-seconds 0 --no-check > $OUT/pmc_${w}_fetch.log 2>&1 || { tail -5 $OUT/pmc_${w}_fetch.log; exit 1; }
-  step pmc $w tcc; rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_${w}_tcc -- python3 $R/bench.py --workload $w --tables 2 --steps 4 --warmup 2 --cpu-seconds 0 --no-check > $OUT/pmc_${w}_tcc.log 2>&1 || { tail -5 $OUT/pmc_${w}_tcc.log; exit 1; }
+  step pmc $w fetch; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_${w}_fetch -- python3 $R/bench.py --workload $w --tables 2 --steps 4 --warmup 2 --cpu-seconds 0 --no-check --no-traffic > $OUT/pmc_${w}_fetch.log 2>&1 || { tail -5 $OUT/pmc_${w}_fetch.log; exit 1; }
+  step pmc $w tcc; rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_${w}_tcc -- python3 $R/bench.py --workload $w --tables 2 --steps 4 --warmup 2 --cpu-seconds 0 --no-check --no-traffic > $OUT/pmc_${w}_tcc.log 2>&1 || { tail -5 $OUT/pmc_${w}_tcc.log; exit 1; }
 done
 step shard timeline; $R/tools/timeline_shard.sh $TAG/shard 4 > $OUT/shard_timeline.log 2>&1 || { tail -5 $OUT/shard_timeline.log; exit 1; }
 tail -30 $OUT/shard_timeline.log
