@@ -166,6 +166,32 @@ def test_bucket_and_bitmap_views(vc, oracle, bits, m, signext):
             assert np.array_equal(words, exp_words)
 
 
+@pytest.mark.parametrize("n", [1, 63, 4095, 4096, 4097, 16383, 16384, 16385, 50001])
+def test_index_build_sort_is_stable_at_tile_boundaries(vc, oracle, n):
+    """The builder's hand-written radix sort (vc_sort.hip: 4096-item sub-tiles, 16384-item blocks): the WHOLE id array
+    of a table, bucket by bucket, for record counts around its tile sizes -- 8-bit substrings (one pass, every bucket
+    enumerated), 16-bit (two passes) and 32-bit (four passes, sampled)."""
+    rng = np.random.default_rng(n)
+    for bits, m, tables in ((64, 8, (0, 7)), (64, 4, (1,)), (128, 4, (2,))):
+        codes = oracle.gen_codes(n, bits, 77 + n, kind=0)
+        mo = oracle.MihOracle(codes, m, key_mode=1, id_base=0)
+        with vc.Engine(bits, capacity=n, n_tables=m) as e:
+            e.add_codes(codes)
+            e.build_index()
+            for t in tables:
+                keys = sorted({mo.key(codes[i], t) for i in range(n)})
+                if len(keys) > 300:
+                    keys = [keys[i] for i in sorted(set(rng.integers(0, len(keys), size=120).tolist()) | {0, len(keys) - 1})]
+                seen = 0
+                for key in keys:
+                    exp = mo.bucket(t, key)
+                    ids, bcodes, total = e.get_bucket(t, key, cap=1 << 16)
+                    assert total == len(exp) and np.array_equal(ids, exp), (bits, m, t, key)
+                    seen += total
+                if bits // m == 8:
+                    assert seen == n
+
+
 def test_mih_overflow_recovery(vc, oracle):
     """a shell whose candidates overflow the ring is re-run with a tightened limit; results unchanged."""
     n, bits, m, k = 80000, 128, 4, 100

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libverticut_gpu.so")
-SOURCES = ["vc_scan.hip", "vc_mih.hip", "vc_engine.hip"]
+SOURCES = ["vc_scan.hip", "vc_mih.hip", "vc_sort.hip", "vc_engine.hip"]
 HEADERS = ["vc_common.hpp", "vc_internal.hpp", "vc_mih.hpp", os.path.join("..", "..", "include", "verticut_gpu.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-pass-failed"]
 

@@ -68,6 +68,16 @@ hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, 
                              const uint32_t* d_count, const uint32_t* d_hist, uint32_t hist_stride, uint32_t qs, uint32_t* d_scratch,
                              uint64_t* d_out, uint32_t* d_out_count, uint32_t* d_clean_tau, uint32_t* d_clean_shist,
                              uint64_t clean_copy_stride, uint32_t clean_copies, uint32_t n_cu, hipStream_t s);
+// ---- vc_sort.hip: the index builder's primitives (hand-written; no device library is linked) --------------------
+// exclusive prefix sum of L uint32 (in place allowed); d_work: vc_scan_work_words(L) words
+size_t vc_scan_work_words(uint64_t L);
+hipError_t vc_exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t L, uint32_t* d_work, hipStream_t s);
+// stable LSD radix sort of n (key, value) pairs by the low key_bits bits of the key (8-bit digits).  Input in
+// (keys[0], vals[0]); the passes ping-pong between the two buffer pairs and the result is in pair
+// (vc_radix_sort_passes(key_bits) & 1).  d_work: vc_radix_sort_work_words(n) words.
+uint32_t vc_radix_sort_passes(uint32_t key_bits);
+size_t vc_radix_sort_work_words(uint64_t n);
+hipError_t vc_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint64_t n, uint32_t key_bits, uint32_t* d_work, hipStream_t s);
 // n_lists x [nq][k] sorted lists -> merged top-k
 hipError_t vc_launch_select_lists(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* d_out,
                                   uint32_t* d_out_count, hipStream_t s);

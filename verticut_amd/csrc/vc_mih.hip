@@ -19,10 +19,11 @@
 //                 + offsets[U + 1] indexed by rank(key) among the U non-empty buckets
 //   bitmap is kept for every s (it is the reference's own prefilter structure, bit v of word v/32).
 // ============================================================================
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstring>
 
 #include "vc_internal.hpp"
 #include "vc_mih.hpp"
@@ -1217,8 +1218,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
   const uint64_t nn = std::max<uint64_t>(n, 1);
 
   uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr;
-  void* d_temp = nullptr;
-  size_t temp_bytes = 0, scan_bytes = 0;
+  uint32_t* d_temp = nullptr;      // work area of the sort and of the scans (vc_sort.hip)
   uint32_t* d_scan_in = nullptr;   // counts (direct) or blockpop (ranked)
 #define B_CHECK(call)                                                                     \
   do {                                                                                    \
@@ -1233,12 +1233,11 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
   B_CHECK(dalloc((void**)&k_in, nn * 4, false));
   B_CHECK(dalloc((void**)&k_out, nn * 4, false));
   B_CHECK(dalloc((void**)&v_in, nn * 4, false));
-  B_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, k_in, k_out, v_in, v_in, (int64_t)n, 0, (int)sbits, s));
   const uint64_t scan_n = sbits == 32 ? (1ull << 24) : nkeyspace + 1;
-  B_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, k_in, k_in, (int64_t)scan_n, s));
-  temp_bytes = std::max(temp_bytes, scan_bytes);
-  B_CHECK(dalloc(&d_temp, temp_bytes, false));
+  const size_t temp_words = std::max(vc_radix_sort_work_words(n), vc_scan_work_words(scan_n));
+  B_CHECK(dalloc((void**)&d_temp, temp_words * 4, false));
   B_CHECK(dalloc((void**)&d_scan_in, (scan_n + 1) * 4, false));
+  const uint32_t passes = vc_radix_sort_passes(sbits);
 
   for (uint32_t t = 0; t < m; ++t) {
     uint32_t *ids = nullptr, *bitmap = nullptr, *offsets = nullptr, *blockrank = nullptr;
@@ -1247,11 +1246,16 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
     B_CHECK(hipMemsetAsync(bitmap, 0, bm_words * 4, s));
     const uint32_t bitpos = t * sbits;
     if (n) {
+      // stable LSD radix sort by key (vc_sort.hip): ids stay ascending inside a bucket = append order of
+      // build_hash_tables.cc:54-63.  The passes ping-pong; the buffers are ordered so that the last pass lands in
+      // (k_out, ids).
+      uint32_t* kb[2] = {k_in, k_out};
+      uint32_t* vb[2] = {v_in, ids};
+      if ((passes & 1u) == 0) { std::swap(kb[0], kb[1]); std::swap(vb[0], vb[1]); }
       hipLaunchKernelGGL(mih_keys_kernel, dim3(grid_for(n, n_cu)), dim3(256), 0, s, d_cols + (uint64_t)(bitpos >> 6) * stride, n,
-                         bitpos & 63, mask, k_in, v_in);
+                         bitpos & 63, mask, kb[0], vb[0]);
       B_CHECK(hipGetLastError());
-      // stable LSD radix sort by key: ids stay ascending inside a bucket = append order of build_hash_tables.cc:54-63
-      B_CHECK(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, k_in, k_out, v_in, ids, (int64_t)n, 0, (int)sbits, s));
+      B_CHECK(vc_radix_sort_pairs(kb, vb, n, sbits, d_temp, s));   // result in pair (passes & 1) = (k_out, ids)
     }
     VcTableView tv{};
     if (sbits < 32) {
@@ -1261,7 +1265,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
         hipLaunchKernelGGL(mih_runs_kernel, dim3(grid_for(n, n_cu)), dim3(256), 0, s, k_out, n, bitmap, d_scan_in);
         B_CHECK(hipGetLastError());
       }
-      B_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_scan_in, offsets, (int64_t)(nkeyspace + 1), s));
+      B_CHECK(vc_exclusive_scan_u32(d_scan_in, offsets, nkeyspace + 1, d_temp, s));
       tv.n_unique = 0;
     } else {
       if (n) {
@@ -1272,7 +1276,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
       B_CHECK(dalloc((void**)&blockrank, (size_t)nblocks * 4, true));
       hipLaunchKernelGGL(mih_blockpop_kernel, dim3(n_cu * 16), dim3(256), 0, s, bitmap, nblocks, d_scan_in);
       B_CHECK(hipGetLastError());
-      B_CHECK(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_scan_in, blockrank, (int64_t)nblocks, s));
+      B_CHECK(vc_exclusive_scan_u32(d_scan_in, blockrank, nblocks, d_temp, s));
       uint32_t last_rank = 0, last_pop = 0;
       B_CHECK(hipMemcpyAsync(&last_rank, blockrank + nblocks - 1, 4, hipMemcpyDeviceToHost, s));
       B_CHECK(hipMemcpyAsync(&last_pop, d_scan_in + nblocks - 1, 4, hipMemcpyDeviceToHost, s));
