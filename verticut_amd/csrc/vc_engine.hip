@@ -90,6 +90,7 @@ static int grow(vc_engine* e, T** p, size_t* have, size_t need) {
 static void read_knobs(VcKnobs* k) {
   if (const char* w = getenv("VC_SCAN_WRAP")) k->scan_wrap = (uint32_t)atoi(w);
   if (const char* w = getenv("VC_SCAN_DIAG")) k->scan_diag = (uint32_t)atoi(w);
+  if (const char* w = getenv("VC_SCAN_TRACE")) k->scan_trace = atoi(w) != 0;
   if (const char* s2 = getenv("VC_SAMPLE2")) { k->sample2_set = true; k->sample2 = strtoull(s2, nullptr, 10); }
   if (const char* s1 = getenv("VC_SAMPLE1")) { k->sample1_set = true; k->sample1 = strtoull(s1, nullptr, 10); }
   if (const char* sh = getenv("VC_SCAN_SHAPE")) {
@@ -574,7 +575,33 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
   const uint32_t every = (e->cfg.flags & VC_FLAG_LEAN_TIMING) ? std::max(e->cfg.timing_sample, 1u) : 1u;
   if (e->scan_event_tick++ % every == 0) ev_pair(e, &a, &bb);
   if (a) VC_HIP(e, hipEventRecord(a, e->stream));
+  uint64_t* d_trace = nullptr;
+  const uint32_t trace_blocks = 8192;
+  if (e->knobs.scan_trace) {   // dev knob, diagnostic build only: when does every block of the persistent grid start and end
+    VC_HIP(e, hipMalloc((void**)&d_trace, trace_blocks * 16));
+    VC_HIP(e, hipMemsetAsync(d_trace, 0, trace_blocks * 16, e->stream));
+    p.trace = d_trace;
+  }
   VC_HIP(e, vc_launch_scan(p, e->W, e->n_cu, e->scan_blocks, &e->knobs, e->stream));
+  if (d_trace) {
+    std::vector<uint64_t> h(trace_blocks * 2);
+    VC_HIP(e, hipMemcpyAsync(h.data(), d_trace, trace_blocks * 16, hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(e, hipStreamSynchronize(e->stream));
+    (void)hipFree(d_trace);
+    std::vector<double> st, en;
+    uint64_t t0 = UINT64_MAX;
+    for (uint32_t i = 0; i < trace_blocks; ++i)
+      if (h[2 * i] && h[2 * i + 1]) t0 = std::min(t0, h[2 * i]);
+    for (uint32_t i = 0; i < trace_blocks; ++i)
+      if (h[2 * i] && h[2 * i + 1]) { st.push_back((h[2 * i] - t0) * 0.01); en.push_back((h[2 * i + 1] - t0) * 0.01); }   // 100 MHz -> us
+    if (!st.empty()) {
+      std::sort(st.begin(), st.end());
+      std::sort(en.begin(), en.end());
+      auto q = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+      fprintf(stderr, "[scan trace] %zu blocks, qt %u: start us min/p50/p90/max %.1f %.1f %.1f %.1f | end us min/p10/p50/p90/p99/max %.1f %.1f %.1f %.1f %.1f %.1f\n",
+              st.size(), qt, q(st, 0), q(st, .5), q(st, .9), q(st, 1), q(en, 0), q(en, .1), q(en, .5), q(en, .9), q(en, .99), q(en, 1));
+    }
+  }
   if (a) {
     VC_HIP(e, hipEventRecord(bb, e->stream));
     e->ev_scans.emplace_back(a, bb);

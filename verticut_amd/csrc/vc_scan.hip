@@ -527,6 +527,9 @@ __global__ void __launch_bounds__(BLK, MINW ? MINW : (BLK == 512 ? 2 : ((W >= 4 
 
   uint64_t chunk = blockIdx.x;
   if (chunk >= p.nchunks) return;
+#if VC_SCAN_DIAGNOSTICS
+  if (p.trace && threadIdx.x == 0) p.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int T = U * W;  // loads per tile
   if constexpr (NB == 1) {
     // single register buffer: memory latency is covered by the other waves of the SIMD (more of them fit)
@@ -566,6 +569,9 @@ __global__ void __launch_bounds__(BLK, MINW ? MINW : (BLK == 512 ? 2 : ((W >= 4 
       if ((chunk += G) >= p.nchunks) break;
     }
   }
+#if VC_SCAN_DIAGNOSTICS
+  if (p.trace && threadIdx.x == 0) p.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
