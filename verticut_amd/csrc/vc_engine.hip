@@ -594,6 +594,18 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
       if (h[2 * i] && h[2 * i + 1]) t0 = std::min(t0, h[2 * i]);
     for (uint32_t i = 0; i < trace_blocks; ++i)
       if (h[2 * i] && h[2 * i + 1]) { st.push_back((h[2 * i] - t0) * 0.01); en.push_back((h[2 * i + 1] - t0) * 0.01); }   // 100 MHz -> us
+    {   // per XCD (blocks map to XCDs round-robin, blockIdx % 8): when does its last block end, and the mean end of its blocks
+      double mx[8] = {}, sum[8] = {};
+      uint32_t cnt[8] = {};
+      for (uint32_t i = 0; i < trace_blocks; ++i)
+        if (h[2 * i] && h[2 * i + 1] && h[2 * i + 1] - t0 < (1ull << 40)) {
+          const double en_us = (h[2 * i + 1] - t0) * 0.01;
+          mx[i & 7] = std::max(mx[i & 7], en_us); sum[i & 7] += en_us; ++cnt[i & 7];
+        }
+      fprintf(stderr, "[scan trace] per XCD last end / mean end us:");
+      for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f/%.0f", mx[x], cnt[x] ? sum[x] / cnt[x] : 0.0);
+      fprintf(stderr, "\n");
+    }
     if (!st.empty()) {
       std::sort(st.begin(), st.end());
       std::sort(en.begin(), en.end());

@@ -570,6 +570,11 @@ __global__ void __launch_bounds__(BLK, MINW ? MINW : (BLK == 512 ? 2 : ((W >= 4 
     }
   }
 #if VC_SCAN_DIAGNOSTICS
+  // The cursor's last load (a re-read of the block's final chunk) is never consumed and still in flight here: to the
+  // compiler its registers are free, and anything it places in them now is overwritten when the load lands (an exit
+  // routine that was tried here -- a call with its pointer argument in v[0:1] -- faulted exactly so).  Code after the
+  // loop must drain first; the plain kernel has none.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (p.trace && threadIdx.x == 0) p.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
