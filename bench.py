@@ -295,8 +295,8 @@ def run_headline(args, env, emit, backend_factory=None):
         env.dist.init_process_group(env.backend, rank=0, world_size=1, **({"device_id": env.device} if env.backend == "nccl" else {}))
         env.own_group = True
     engine_kw = {}
-    if world > 1:        # shards are small (0.35 ms per pass): time every 4th verify launch only, an event record costs ~5 us
-        engine_kw["timing_sample"] = int(os.environ.get("VC_BENCH_TIMING_SAMPLE", "4"))
+    if world > 1:        # shards are small (0.35 ms per pass): time every 8th verify launch only, an event record costs ~5 us
+        engine_kw["timing_sample"] = int(os.environ.get("VC_BENCH_TIMING_SAMPLE", "8"))
     elif os.environ.get("VC_BENCH_TIMING_SAMPLE"):
         engine_kw["timing_sample"] = int(os.environ["VC_BENCH_TIMING_SAMPLE"])
     if os.environ.get("VC_BENCH_SCAN_BLOCKS"):      # dev: cap the persistent verify grid (leave block slots to other kernels)
