@@ -103,6 +103,7 @@ struct VcScanParams {
   uint32_t diag;            // diagnostic only (VC_SCAN_DIAG): N > 0 replaces the verify arithmetic by s_sleep N per query
   uint32_t qs;              // stride, in words, between consecutive queries' entries of tau[] and count[] (>= 1)
   uint64_t* trace;          // diagnostic only (VC_SCAN_TRACE): [grid][2] s_memrealtime at block start / end
+  uint64_t resident;        // chunks [0, resident) are read with plain (Infinity-Cache-allocating) loads, the rest non-temporal
 };
 // The linear path gives every query its own 128-byte line for its threshold and for its ring cursor: both are read /
 // updated coherently by every wave that enters the rare path, coherent traffic to one line is served by ONE memory

@@ -91,6 +91,7 @@ static void read_knobs(VcKnobs* k) {
   if (const char* w = getenv("VC_SCAN_WRAP")) k->scan_wrap = (uint32_t)atoi(w);
   if (const char* w = getenv("VC_SCAN_DIAG")) k->scan_diag = (uint32_t)atoi(w);
   if (const char* w = getenv("VC_SCAN_TRACE")) k->scan_trace = atoi(w) != 0;
+  if (const char* w = getenv("VC_SCAN_RESIDENT_MB")) k->resident_mb = std::max(0, atoi(w));
   if (const char* s2 = getenv("VC_SAMPLE2")) { k->sample2_set = true; k->sample2 = strtoull(s2, nullptr, 10); }
   if (const char* s1 = getenv("VC_SAMPLE1")) { k->sample1_set = true; k->sample1 = strtoull(s1, nullptr, 10); }
   if (const char* sh = getenv("VC_SCAN_SHAPE")) {
@@ -521,6 +522,7 @@ struct LinearBufs {
 // Queries whose bootstrap is done by ONE pair of sampling launches: the tiles of a group share them (the stage
 // kernels read the sampled prefix once per 32 queries instead of once per tile) and one select launch.
 #define VC_GROUP_QUERIES 64u
+#define VC_RESIDENT_MB_DEFAULT 240   // of the 256 MB Infinity Cache (profiles/r02_sweeps.md: 224-256 MB best, 320 MB thrashes)
 
 static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
   b->hs = (e->bits + 1 + 7) & ~7u;
@@ -569,6 +571,10 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
   p.limit = d_limit;
   p.wrap = e->knobs.scan_wrap;   // diagnostic build only, results are wrong by design
   p.diag = e->knobs.scan_diag;
+  {   // Infinity-Cache-resident prefix (see the load in vc_scan_kernel)
+    const uint64_t mb = e->knobs.resident_mb < 0 ? VC_RESIDENT_MB_DEFAULT : (uint64_t)e->knobs.resident_mb;
+    p.resident = (mb << 20) / (sh.chunk_items() * (e->bits / 8));
+  }
   hipEvent_t a = nullptr, bb = nullptr;
   // VC_FLAG_LEAN_TIMING with vc_config.timing_sample = N > 1: only every N-th verify launch is bracketed by events
   // (an event record is a barrier packet, ~4-5 us each; a 125 M-code shard step is 0.35 ms)
@@ -578,15 +584,22 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
   uint64_t* d_trace = nullptr;
   const uint32_t trace_blocks = 8192;
   if (e->knobs.scan_trace) {   // dev knob, diagnostic build only: when does every block of the persistent grid start and end
-    VC_HIP(e, hipMalloc((void**)&d_trace, trace_blocks * 16));
-    VC_HIP(e, hipMemsetAsync(d_trace, 0, trace_blocks * 16, e->stream));
+    VC_HIP(e, hipMalloc((void**)&d_trace, trace_blocks * 16 + 256));   // + the rare-path counters
+    VC_HIP(e, hipMemsetAsync(d_trace, 0, trace_blocks * 16 + 256, e->stream));
     p.trace = d_trace;
   }
   VC_HIP(e, vc_launch_scan(p, e->W, e->n_cu, e->scan_blocks, &e->knobs, e->stream));
   if (d_trace) {
-    std::vector<uint64_t> h(trace_blocks * 2);
-    VC_HIP(e, hipMemcpyAsync(h.data(), d_trace, trace_blocks * 16, hipMemcpyDeviceToHost, e->stream));
+    std::vector<uint64_t> h(trace_blocks * 2 + 32);
+    VC_HIP(e, hipMemcpyAsync(h.data(), d_trace, trace_blocks * 16 + 256, hipMemcpyDeviceToHost, e->stream));
     VC_HIP(e, hipStreamSynchronize(e->stream));
+    {
+      const uint32_t* c = (const uint32_t*)(h.data() + trace_blocks * 2);
+      fprintf(stderr, "[scan trace] rare path: %u entries, %u of them appended %u items, %u re-cuts (%u queries)\n", c[0], c[1], c[2], c[3], qt);
+      fprintf(stderr, "[scan trace] appended items by pass of the chunk loop:");
+      for (int i = 0; i < 56; ++i) fprintf(stderr, " %u", c[8 + i]);
+      fprintf(stderr, "\n");
+    }
     (void)hipFree(d_trace);
     std::vector<double> st, en;
     uint64_t t0 = UINT64_MAX;

@@ -18,6 +18,7 @@ struct VcKnobs {
   int mih_bcodes = -1;                        // VC_MIH_BCODES: -1 auto, 0 / 1 forced
   int scan_small = 1;                         // VC_SCAN_SMALL=0: the general (LDS-streamed) query loop for every tile size
   uint64_t mih_budget = 0;                    // VC_MIH_BUDGET: probes per query run inside mih_query_kernel (0 = automatic)
+  int resident_mb = -1;                       // VC_SCAN_RESIDENT_MB: database prefix kept in the Infinity Cache by the verify pass (-1 = default)
   bool scan_trace = false;                    // VC_SCAN_TRACE=1 (diagnostic build): per-block start / end times of the verify kernel
   int mih_host_loop = 0;                      // VC_MIH_HOST_LOOP=1: one host round trip per shell (the round-1 loop)
 };

@@ -296,6 +296,8 @@ struct VcScanRare {
   uint64_t* buf;
   const uint64_t* limit;
   uint32_t id_base, k, cap, hist_stride, qs;
+  uint32_t* dbg;   // diagnostic build + VC_SCAN_TRACE: [0] rare-path entries, [1] entries that appended, [2] appended items,
+                   // [3] re-cuts, [8..63] appended items by pass of the block's chunk loop
 };
 
 template <int W, int U, int BLK>
@@ -313,6 +315,10 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
   uint32_t* hist = p.hist + (uint64_t)q * p.hist_stride;
   uint32_t seen = 0;   // ring fill after this wave's last append (wave-uniform)
   bool recut = false;  // an append of this wave crossed a VC_SCAN_RECUT_EVERY boundary of the ring fill
+#if VC_SCAN_DIAGNOSTICS
+  uint32_t dbg_items = 0;
+  if (p.dbg && lane == 0) atomicAdd(p.dbg + 0, 1u);
+#endif
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     uint64_t a[W], b[W];
@@ -334,6 +340,9 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
     base = __builtin_amdgcn_readfirstlane(base);
     slot += base;
     seen = base + total;
+#if VC_SCAN_DIAGNOSTICS
+    dbg_items += total;
+#endif
     recut = recut || (base / VC_SCAN_RECUT_EVERY != seen / VC_SCAN_RECUT_EVERY) || (base < p.k && seen >= p.k);
     if (oka) {
       if (slot < p.cap) ring[slot] = pa;
@@ -348,6 +357,16 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
   // re-derive the chip-wide threshold from the histogram of everything appended so far -- not on every entry: the
   // histogram lines are read coherently by every wave that gets here, and same-line coherent accesses serialise in
   // L2 (~27 ns each), so only the wave whose append crosses a multiple of VC_SCAN_RECUT_EVERY entries does it
+#if VC_SCAN_DIAGNOSTICS
+  if (p.dbg && lane == 0) {
+    if (dbg_items) {
+      atomicAdd(p.dbg + 1, 1u);
+      atomicAdd(p.dbg + 2, dbg_items);
+      atomicAdd(p.dbg + 8 + min((uint32_t)(chunk_base / (2ull * BLK * U) / gridDim.x), 55u), dbg_items);
+    }
+    if (seen >= p.k && recut) atomicAdd(p.dbg + 3, 1u);
+  }
+#endif
   if (seen >= p.k && recut) {
     const uint32_t cut = vc_hist_cut(hist, t + 1, p.k, true);
     if (cut < t) {
@@ -388,7 +407,8 @@ __global__ void __launch_bounds__(BLK, MINW ? MINW : (BLK == 512 ? 2 : ((W >= 4 
   __syncthreads();
 
   constexpr uint64_t CH = 2ull * BLK * U;
-  const VcScanRare rare{p.n, p.tau, p.count, p.hist, p.buf, p.limit, p.id_base, p.k, p.cap, p.hist_stride, p.qs};
+  const VcScanRare rare{p.n, p.tau, p.count, p.hist, p.buf, p.limit, p.id_base, p.k, p.cap, p.hist_stride, p.qs,
+                        (VC_SCAN_DIAGNOSTICS && p.trace) ? (uint32_t*)(p.trace + 2 * 8192) : nullptr};
   vc_u64x2 ra[U][W], rb[NB >= 2 ? U : 1][W], rc[NB >= 3 ? U : 1][W];
 
   // Prefetch cursor: the chunk the next load() fetches.  Tile loads are issued by hand (inline asm): the address is a
@@ -416,7 +436,13 @@ __global__ void __launch_bounds__(BLK, MINW ? MINW : (BLK == 512 ? 2 : ((W >= 4 
         // read of it, should it ever compute the base that way; an SGPR written by the SALU has no such hazard.
         const uint64_t* sb;
 #if VC_SCAN_NT
-        asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1 nt" : "=&v"(r[u][j]), "=&s"(sb) : "v"(lane_off), "s"(sbase));
+        // The stream is non-temporal -- except the first p.resident chunks of the database, read with plain loads: nt
+        // loads do not allocate in the 256 MB Infinity Cache, plain ones do, so that prefix (and nothing else the pass
+        // reads) stays cache-resident from one pass to the next and costs no HBM traffic after the first.
+        if (pf < p.resident)
+          asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1" : "=&v"(r[u][j]), "=&s"(sb) : "v"(lane_off), "s"(sbase));
+        else
+          asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1 nt" : "=&v"(r[u][j]), "=&s"(sb) : "v"(lane_off), "s"(sbase));
 #else
         asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1" : "=&v"(r[u][j]), "=&s"(sb) : "v"(lane_off), "s"(sbase));
 #endif
@@ -1161,12 +1187,16 @@ hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t ld
     const uint32_t grid = (uint32_t)std::min<uint64_t>(p.nchunks, resident_grid(kern, B_, lds, n_cu, want)); \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(B_), lds, s, p);                                              \
   }
+  // (shapes with more than 8 tile loads per lane and buffer are never picked -- vc_scan_pick_shape -- and not built:
+  // they spill, and a spilling kernel is unsafe next to hand-issued loads)
 #define VC_SCAN_CASE(U_, B_)                                                                     \
-  if (sh.unroll == U_ && sh.blk == B_) {                                                         \
-    if (sh.dbuf == 3) VC_LAUNCH(3, U_, B_)                                                       \
-    else if (sh.dbuf == 2) VC_LAUNCH(2, U_, B_)                                                  \
-    else VC_LAUNCH(1, U_, B_)                                                                    \
-    return hipGetLastError();                                                                    \
+  if constexpr (U_ * W <= 8) {                                                                   \
+    if (sh.unroll == U_ && sh.blk == B_) {                                                       \
+      if (sh.dbuf == 3) VC_LAUNCH(3, U_, B_)                                                     \
+      else if (sh.dbuf == 2) VC_LAUNCH(2, U_, B_)                                                \
+      else VC_LAUNCH(1, U_, B_)                                                                  \
+      return hipGetLastError();                                                                  \
+    }                                                                                            \
   }
   VC_SCAN_CASE(4, 256)
   VC_SCAN_CASE(2, 256)
