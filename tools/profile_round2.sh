@@ -29,7 +29,7 @@ for w in c2 knn_mih; do   # (c2: the m = 2 engine only, so that the per-launch a
   step pmc $w fetch; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_${w}_fetch -- python3 $R/bench.py --workload $w --tables 2 --steps 4 --warmup 2 --cpu-seconds 0 --no-check --no-traffic > $OUT/pmc_${w}_fetch.log 2>&1 || { tail -5 $OUT/pmc_${w}_fetch.log; exit 1; }
   step pmc $w tcc; rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_${w}_tcc -- python3 $R/bench.py --workload $w --tables 2 --steps 4 --warmup 2 --cpu-seconds 0 --no-check --no-traffic > $OUT/pmc_${w}_tcc.log 2>&1 || { tail -5 $OUT/pmc_${w}_tcc.log; exit 1; }
 done
-step shard timeline; $R/tools/timeline_shard.sh $TAG/shard 4 > $OUT/shard_timeline.log 2>&1 || { tail -5 $OUT/shard_timeline.log; exit 1; }
+step shard timeline; $R/tools/timeline_shard.sh $TAG/shard 8 > $OUT/shard_timeline.log 2>&1 || { tail -5 $OUT/shard_timeline.log; exit 1; }
 tail -30 $OUT/shard_timeline.log
 # keep what is merged back small: the raw traces are large
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete

@@ -645,10 +645,11 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
   // the verify kernel's first tiles do not flood the ring / histogram atomics from every wave at once (that flood cost
   // ~0.4 ms per launch while eight queries shared one line for their ring cursors and one for their thresholds).
   // Round 1 ran two stages (64 K codes exactly, then 2 M codes counting only distances <= tau1): 4 launches, 26 us.
-  // With one line per query the flood is mild and the threshold of ONE exact stage over 1.5 M codes starts the verify
-  // kernel just as well -- 2 launches, 18 us; a 125 M-code shard step 0.397 -> 0.384 ms, 1e9 unchanged
-  // (profiles/r02_sweeps.md).  The refining stage stays selectable (VC_SAMPLE2, tests).
-  uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(std::max<uint64_t>(262144, 64ull * k), std::min<uint64_t>(e->n / 16, 1572864)));
+  // With one line per query the flood is mild and the threshold of ONE exact stage over 1 M codes starts the verify
+  // kernel just as well -- 2 launches, 15 us; a 125 M-code shard step 0.397 -> 0.384 ms, 1e9 unchanged
+  // (profiles/r02_sweeps.md; below 512 K codes the verify pass pays for the looser threshold, beyond 1 M nothing is
+  // gained -- an exact threshold makes a 1e9 pass no faster).  The refining stage stays selectable (VC_SAMPLE2, tests).
+  uint64_t sample = std::min<uint64_t>(e->n, std::max<uint64_t>(std::max<uint64_t>(262144, 64ull * k), std::min<uint64_t>(e->n / 16, 1048576)));
   uint64_t sample2 = 0;
   if (e->knobs.sample2_set) sample2 = std::min<uint64_t>(e->n, e->knobs.sample2);   // dev/test knob VC_SAMPLE2
   if (e->knobs.sample1_set) sample = std::min<uint64_t>(e->n, e->knobs.sample1);      // dev/test knob VC_SAMPLE1
