@@ -212,3 +212,26 @@ def test_results_do_not_depend_on_the_column_stride(vc, oracle, monkeypatch):
         else:
             assert all(np.array_equal(a, b) for a, b in zip(got[:4], ref[:4]))
             assert all(np.array_equal(a, b) for a, b in zip(got[4], ref[4]))
+
+@pytest.mark.parametrize("bits", [64, 128, 512])
+def test_cache_resident_prefix_does_not_change_results(vc, oracle, monkeypatch, bits):
+    """The verify kernel reads a prefix of the database with plain loads (it stays in the Infinity Cache from pass to
+    pass) and the rest non-temporal (VC_SCAN_RESIDENT_MB, default 240): same bytes, same results wherever the boundary
+    falls -- no prefix, a boundary inside the database (1 MB of 3.2-25 MB), everything resident -- and on repeated passes."""
+    n, k = 400_000, 50
+    codes = oracle.gen_codes(n, bits, 9, kind=1, n_centres=300, max_flips=9)
+    rng = np.random.default_rng(bits)
+    q = codes[rng.integers(0, n, size=9)].copy()
+    q[:, 1] ^= 0x21
+    exp = [oracle.linear_knn(codes, q[i], k) for i in range(len(q))]
+    for mb in ("0", "1", None):
+        if mb is None:
+            monkeypatch.delenv("VC_SCAN_RESIDENT_MB", raising=False)
+        else:
+            monkeypatch.setenv("VC_SCAN_RESIDENT_MB", mb)
+        with vc.Engine(bits, capacity=n, query_tile=8) as e:
+            e.add_codes(codes)
+            for _ in range(2):
+                got, cnt = e.search_knn(q, k)
+                for i in range(len(q)):
+                    assert np.array_equal(got[i, : cnt[i]], exp[i]), (mb, i)
