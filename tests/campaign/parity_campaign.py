@@ -57,6 +57,13 @@ def main():
             os.environ["VC_SCAN_SHAPE"] = shape
         else:
             os.environ.pop("VC_SCAN_SHAPE", None)
+        # the verify kernel's cache-resident prefix (plain loads below the boundary, non-temporal above): default 240 MB,
+        # none, or a boundary inside the database
+        res = (None, None, "0", "1", "4")[i % 5]
+        if res is None:
+            os.environ.pop("VC_SCAN_RESIDENT_MB", None)
+        else:
+            os.environ["VC_SCAN_RESIDENT_MB"] = res
         cand_cap = int(rng.choice([0, 0, 4 * k, 4096]))
         with vc.Engine(bits, capacity=n, id_base=id_base, query_tile=qt, cand_cap=cand_cap) as e:
             if kind == 0 and i % 2 == 0:
@@ -71,8 +78,8 @@ def main():
                           (i, r, bits, kind, n, k, nq, qt, shape, cand_cap), flush=True)
                     return 1
                 checked += 1
-        print("ok case %3d bits=%3d kind=%d n=%8d k=%4d nq=%2d qt=%2d shape=%-8s cap=%5d  (%.0f s)" %
-              (i, bits, kind, n, k, nq, qt, shape, cand_cap, time.time() - t_start), flush=True)
+        print("ok case %3d bits=%3d kind=%d n=%8d k=%4d nq=%2d qt=%2d shape=%-8s cap=%5d res=%-4s (%.0f s)" %
+              (i, bits, kind, n, k, nq, qt, shape, cand_cap, res, time.time() - t_start), flush=True)
     print("parity campaign: %d cases, %d queries bit-exact against the oracle in %.0f s" %
           (n_cases, checked, time.time() - t_start), flush=True)
     return 0
