@@ -310,7 +310,8 @@ def run_headline(args, env, emit, backend_factory=None):
         ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, backend=backend_factory(args.bits, lo, hi),
                            force_exchange=force_exchange, bucket=bucket)
     else:
-        ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=env.local_rank, query_tile=Q,
+        qtile = int(os.environ.get("VC_BENCH_QUERY_TILE", Q))   # dev: several verify launches per step (tools/multi_tile.sh)
+        ss = ShardedSearch(args.bits, n_total, rank=rank, world=world, device=env.local_rank, query_tile=qtile,
                            force_exchange=force_exchange, bucket=bucket, **engine_kw)
     ss.add_synthetic(args.seed)
 
@@ -401,7 +402,8 @@ def run_headline(args, env, emit, backend_factory=None):
                 "workload": "BASELINE configs[%d]: %d-bit codes, %.3g-code DB%s, top-%d k-NN, linear verify kernel"
                             % (2 if world == 1 else 3, args.bits, n_total,
                                "" if world == 1 else " sharded %d ways by id range" % world, k),
-                "n_codes": n_total, "bits": args.bits, "k": k, "queries_per_step": Q, "query_tile": Q,
+                "n_codes": n_total, "bits": args.bits, "k": k, "queries_per_step": Q,
+                "query_tile": int(os.environ.get("VC_BENCH_QUERY_TILE", Q)),
                 "query_kind": "uniform random", "seed": args.seed,
                 "parallelism": "1 process/GPU, DB shard per GPU, RCCL all-gather of per-shard top-k + merge kernel"
                                if world > 1 else "single GPU",
