@@ -482,8 +482,21 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 // to the slot arrays and joins the `heavy` list, which the multi-block kernels above continue from shell r_last + 1.
 // =============================================================================================================
 #define MQ_BLK 256u
-#define MQ_G 4u                         // granules / keys per thread per pass
+#define MQ_G 4u                         // keys per thread per pass (<= 16-bit substrings)
 #define MQ_PASS (MQ_BLK * MQ_G)
+// 32-bit substrings: a key = (hi: 32 - LO bits | lo: LO bits), a granule = the 2^LO bitmap bits that share `hi`; LO is a
+// template parameter of the kernel.  Radius search (configs[1]: ~31 K granules per query) runs LO = 9: a granule is one
+// whole 64-byte sector (four 16-byte loads of a lane, the last three hit the line the first one fetched) and shells 0..4
+// of a table are 10 903 sector reads instead of the 15 276 separate sectors of 128-bit granules (+7 % queries/s; the
+// rest of a query's sectors are its ~1 900 bucket look-ups).  k-NN (a few hundred granules per query, a latency chain)
+// keeps LO = 7: one 16-byte load and four mask words per granule (LO = 9 there: -15 %).
+#ifndef MQ_LO_RADIUS
+#define MQ_LO_RADIUS 9u
+#endif
+#ifndef MQ_LO_KNN
+#define MQ_LO_KNN 7u
+#endif
+#define MQ_LO_MAX (MQ_LO_RADIUS > MQ_LO_KNN ? MQ_LO_RADIUS : MQ_LO_KNN)
 #ifndef MQ_HMAX
 #define MQ_HMAX 1024u                   // LDS hit list (non-empty buckets awaiting a drain)
 #endif
@@ -525,15 +538,20 @@ __device__ __forceinline__ uint32_t mq_unrank(const uint32_t* sb, uint32_t j, ui
   return mask;
 }
 
-template <int W>
+template <int W, uint32_t MQ_LO>
 __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kernel(const QueryKernelParams p) {
+  constexpr uint32_t MQ_HI = 32u - MQ_LO;
+  constexpr uint32_t MQ_GW = (1u << MQ_LO) / 32u;                    // 32-bit words per granule
+  constexpr uint32_t MQ_NJ = MQ_LO + 1u;                              // masks per table: j = 0 .. LO flips inside the low part
+  constexpr uint32_t MQ_G32 = MQ_GW >= 16u ? 1u : 16u / MQ_GW;        // granules per thread per pass (64 bytes in flight per lane)
+  constexpr uint32_t MQ_PASS32 = MQ_BLK * MQ_G32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* s_buf = (uint64_t*)smem;                         // [buf_entries] top-k (sorted) | fresh candidates
   uint32_t* s_key = (uint32_t*)(s_buf + p.buf_entries);      // [MQ_HMAX] bucket key, then bucket offset
   uint32_t* s_pref = s_key + MQ_HMAX;                        // [MQ_HMAX + 1] bucket length, then exclusive prefix
   uint32_t* s_meta = s_pref + MQ_HMAX + 1;                   // [MQ_HMAX] table | substring distance << 8
   uint32_t* s_binom = s_meta + MQ_HMAX;                      // [33][MQ_BW]
-  uint32_t* s_mask = s_binom + 33 * MQ_BW;                   // [m][8][4] (32-bit substrings only)
+  uint32_t* s_mask = s_binom + 33 * MQ_BW;                   // [m][MQ_NJ][MQ_GW] (32-bit substrings only)
   __shared__ VcTableView s_tv[64];
   __shared__ uint32_t s_nh, s_ncand, s_seen, s_hits0, s_wsum[MQ_BLK / VC_WAVE];
   __shared__ uint32_t s_segstart[28], s_segh[27], s_segmask[27], s_nseg;
@@ -560,7 +578,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   for (uint32_t i = tid; i < 33 * MQ_BW; i += MQ_BLK) s_binom[i] = c_binom[i / MQ_BW][i % MQ_BW];
   for (uint32_t i = tid; i < m * (sizeof(VcTableView) / 4); i += MQ_BLK) ((uint32_t*)s_tv)[i] = ((const uint32_t*)p.tables)[i];
   if (s == 32)
-    for (uint32_t i = tid; i < m * 32; i += MQ_BLK) s_mask[i] = 0;
+    for (uint32_t i = tid; i < m * MQ_NJ * MQ_GW; i += MQ_BLK) s_mask[i] = 0;
   if (tid == 0) {
     s_nh = 0;
     s_ncand = 0;
@@ -569,20 +587,20 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     s_thresh = knn ? VC_PACK_INF : vc_pack(p.radius + 1, 0);
   }
   __syncthreads();
-  if (s == 32) {   // E_j[t] = { x < 128 : popcount(x ^ qlo_t) = j }; radius search: balls B_j = E_0 | ... | E_j
-    for (uint32_t i = tid; i < m * 128; i += MQ_BLK) {
-      const uint32_t t = i >> 7, x = i & 127u;
-      const uint32_t j = __popc(x ^ (qkey(t) & 127u));
-      atomicOr(&s_mask[(t * 8 + j) * 4 + (x >> 5)], 1u << (x & 31));
+  if (s == 32) {   // E_j[t] = { x < 2^MQ_LO : popcount(x ^ qlo_t) = j }; radius search: balls B_j = E_0 | ... | E_j
+    for (uint32_t i = tid; i < (m << MQ_LO); i += MQ_BLK) {
+      const uint32_t t = i >> MQ_LO, x = i & ((1u << MQ_LO) - 1u);
+      const uint32_t j = __popc(x ^ (qkey(t) & ((1u << MQ_LO) - 1u)));
+      atomicOr(&s_mask[(t * MQ_NJ + j) * MQ_GW + (x >> 5)], 1u << (x & 31));
     }
     __syncthreads();
     if (!knn) {
-      for (uint32_t i = tid; i < m * 4; i += MQ_BLK) {
-        const uint32_t t = i >> 2, w = i & 3u;
+      for (uint32_t i = tid; i < m * MQ_GW; i += MQ_BLK) {
+        const uint32_t t = i / MQ_GW, w = i % MQ_GW;
         uint32_t acc = 0;
-        for (uint32_t j = 0; j < 8; ++j) {
-          acc |= s_mask[(t * 8 + j) * 4 + w];
-          s_mask[(t * 8 + j) * 4 + w] = acc;
+        for (uint32_t j = 0; j < MQ_NJ; ++j) {
+          acc |= s_mask[(t * MQ_NJ + j) * MQ_GW + w];
+          s_mask[(t * MQ_NJ + j) * MQ_GW + w] = acc;
         }
       }
       __syncthreads();
@@ -754,22 +772,23 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   auto scan32 = [&]() {
     const uint32_t per_table = s_segstart[s_nseg];
     const uint32_t total = per_table * m;
-    for (uint32_t base = 0; base < total; base += MQ_PASS) {
-      const uint32_t idx0 = base + tid * MQ_G;
+    for (uint32_t base = 0; base < total; base += MQ_PASS32) {
+      const uint32_t idx0 = base + tid * MQ_G32;
       uint32_t t = 0, rem = 0, seg = 0, hi = 0;
       if (idx0 < total) {
         t = idx0 / per_table;
         rem = idx0 - t * per_table;
         while (rem >= s_segstart[seg + 1]) ++seg;
-        hi = mq_unrank(s_binom, rem - s_segstart[seg], s_segh[seg], 25);
+        hi = mq_unrank(s_binom, rem - s_segstart[seg], s_segh[seg], MQ_HI);
       }
-      uint4 v[MQ_G];
-      uint32_t gr[MQ_G], meta0[MQ_G], mi[MQ_G], qlo[MQ_G];   // meta0 = table | |hi| << 8
+      uint4 v[MQ_G32][MQ_GW / 4];
+      uint32_t gr[MQ_G32], meta0[MQ_G32], mi[MQ_G32], qlo[MQ_G32];   // meta0 = table | |hi| << 8
 #pragma unroll
-      for (uint32_t g = 0; g < MQ_G; ++g) {
+      for (uint32_t g = 0; g < MQ_G32; ++g) {
         const uint32_t idx = idx0 + g;
         gr[g] = 0; meta0[g] = 0; mi[g] = 0; qlo[g] = 0;
-        v[g] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t c = 0; c < MQ_GW / 4; ++c) v[g][c] = make_uint4(0, 0, 0, 0);
         if (idx < total) {
           if (g) {
             ++rem;
@@ -786,23 +805,29 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
             }
           }
           const uint32_t qk = qkey(t);
-          gr[g] = (qk >> 7) ^ hi;
-          qlo[g] = qk & 127u;
+          gr[g] = (qk >> MQ_LO) ^ hi;
+          qlo[g] = qk & ((1u << MQ_LO) - 1u);
           meta0[g] = t | (s_segh[seg] << 8);
-          mi[g] = t * 8 + s_segmask[seg];
-          v[g] = *reinterpret_cast<const uint4*>(s_tv[t].bitmap + ((uint64_t)gr[g] << 2));
+          mi[g] = t * MQ_NJ + s_segmask[seg];
+          const uint4* gp = reinterpret_cast<const uint4*>(s_tv[t].bitmap + (uint64_t)gr[g] * MQ_GW);
+#pragma unroll
+          for (uint32_t c = 0; c < MQ_GW / 4; ++c) v[g][c] = gp[c];
         }
       }
-      uint32_t w[MQ_G][4];
+      uint32_t w[MQ_G32][MQ_GW];
       uint32_t cnt = 0, cnt0 = 0;
 #pragma unroll
-      for (uint32_t g = 0; g < MQ_G; ++g) {
-        const uint32_t* mk = s_mask + mi[g] * 4;
-        w[g][0] = v[g].x & mk[0];
-        w[g][1] = v[g].y & mk[1];
-        w[g][2] = v[g].z & mk[2];
-        w[g][3] = v[g].w & mk[3];
-        const uint32_t c = __popc(w[g][0]) + __popc(w[g][1]) + __popc(w[g][2]) + __popc(w[g][3]);
+      for (uint32_t g = 0; g < MQ_G32; ++g) {
+        const uint32_t* mk = s_mask + mi[g] * MQ_GW;
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t cc = 0; cc < MQ_GW / 4; ++cc) {
+          w[g][4 * cc + 0] = v[g][cc].x & mk[4 * cc + 0];
+          w[g][4 * cc + 1] = v[g][cc].y & mk[4 * cc + 1];
+          w[g][4 * cc + 2] = v[g][cc].z & mk[4 * cc + 2];
+          w[g][4 * cc + 3] = v[g][cc].w & mk[4 * cc + 3];
+          c += __popc(w[g][4 * cc + 0]) + __popc(w[g][4 * cc + 1]) + __popc(w[g][4 * cc + 2]) + __popc(w[g][4 * cc + 3]);
+        }
         cnt += c;
         if ((meta0[g] & 0xFFu) == 0 && idx0 + g < per_table) cnt0 += c;
       }
@@ -819,14 +844,14 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         if (lane == 0 && wtot) wb = atomicAdd(&s_nh, wtot);
         uint32_t pos = __builtin_amdgcn_readfirstlane(wb) + off;
 #pragma unroll
-        for (uint32_t g = 0; g < MQ_G; ++g)
+        for (uint32_t g = 0; g < MQ_G32; ++g)
 #pragma unroll
-          for (uint32_t i = 0; i < 4; ++i)
+          for (uint32_t i = 0; i < MQ_GW; ++i)
             while (w[g][i] && pos < MQ_HMAX) {
               const uint32_t bb = (uint32_t)__ffs((int)w[g][i]) - 1u;
               w[g][i] &= w[g][i] - 1u;
               const uint32_t x = i * 32 + bb;
-              s_key[pos] = (gr[g] << 7) | x;
+              s_key[pos] = (gr[g] << MQ_LO) | x;
               s_meta[pos] = meta0[g] + (__popc(x ^ qlo[g]) << 8);
               ++pos;
               --cnt;
@@ -917,13 +942,13 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     __syncthreads();
     if (tid == 0) {
       uint32_t ns = 0, start = 0;
-      for (uint32_t h = 0; h <= min(r, 25u); ++h) {
+      for (uint32_t h = 0; h <= min(r, MQ_HI); ++h) {
         const uint32_t j = r - h;
-        if (!ball && j > 7) continue;            // a 7-bit low part holds at most 7 flips
+        if (!ball && j > MQ_LO) continue;        // the low part holds at most MQ_LO flips
         s_segstart[ns] = start;
         s_segh[ns] = h;
-        s_segmask[ns] = min(j, 7u);
-        start += s_binom[25 * MQ_BW + h];
+        s_segmask[ns] = min(j, MQ_LO);
+        start += s_binom[MQ_HI * MQ_BW + h];
         ++ns;
       }
       s_segstart[ns] = start;
@@ -1597,18 +1622,24 @@ static hipError_t launch_probe(const ProbeParams& p, uint32_t W, uint32_t n_list
 }
 
 static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits) {
-  return (size_t)buf_entries * 8 + (size_t)(3 * MQ_HMAX + 1) * 4 + (size_t)33 * MQ_BW * 4 + (sbits == 32 ? (size_t)m * 32 * 4 : 0) + 16;
+  return (size_t)buf_entries * 8 + (size_t)(3 * MQ_HMAX + 1) * 4 + (size_t)33 * MQ_BW * 4 + (sbits == 32 ? (size_t)m * (MQ_LO_MAX + 1) * ((1u << MQ_LO_MAX) / 32u) * 4 : 0) + 16;   // masks sized for the widest granule
 }
 
 static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s) {
   const size_t lds = query_kernel_lds(p.buf_entries, p.m, p.sbits);
+#define MQ_LAUNCH(W_)                                                                                           \
+  case W_:                                                                                                      \
+    if (p.mode == MQ_MODE_RADIUS) hipLaunchKernelGGL((mih_query_kernel<W_, MQ_LO_RADIUS>), dim3(nq), dim3(MQ_BLK), lds, s, p); \
+    else hipLaunchKernelGGL((mih_query_kernel<W_, MQ_LO_KNN>), dim3(nq), dim3(MQ_BLK), lds, s, p);              \
+    break;
   switch (W) {
-    case 1: hipLaunchKernelGGL(mih_query_kernel<1>, dim3(nq), dim3(MQ_BLK), lds, s, p); break;
-    case 2: hipLaunchKernelGGL(mih_query_kernel<2>, dim3(nq), dim3(MQ_BLK), lds, s, p); break;
-    case 4: hipLaunchKernelGGL(mih_query_kernel<4>, dim3(nq), dim3(MQ_BLK), lds, s, p); break;
-    case 8: hipLaunchKernelGGL(mih_query_kernel<8>, dim3(nq), dim3(MQ_BLK), lds, s, p); break;
+    MQ_LAUNCH(1)
+    MQ_LAUNCH(2)
+    MQ_LAUNCH(4)
+    MQ_LAUNCH(8)
     default: return hipErrorInvalidValue;
   }
+#undef MQ_LAUNCH
   return hipGetLastError();
 }
 
