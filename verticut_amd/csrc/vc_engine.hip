@@ -103,6 +103,7 @@ static void read_knobs(VcKnobs* k) {
   k->mih_trace = getenv("VC_MIH_TRACE") != nullptr;
   if (const char* r = getenv("VC_DEVICE_RECOVER")) k->device_recover = atoi(r) != 0;
   if (const char* v = getenv("VC_MIH_BCODES")) k->mih_bcodes = atoi(v) != 0;
+  if (const char* v = getenv("VC_MIH_BENT")) k->mih_bent = atoi(v) != 0;
   if (const char* v = getenv("VC_MIH_HOST_LOOP")) k->mih_host_loop = atoi(v);
   if (const char* v = getenv("VC_SCAN_SMALL")) k->scan_small = atoi(v);
   if (const char* v = getenv("VC_MIH_BUDGET")) k->mih_budget = strtoull(v, nullptr, 10);

@@ -16,6 +16,7 @@ struct VcKnobs {
   bool mih_trace = false;                     // VC_MIH_TRACE
   bool device_recover = true;                 // VC_DEVICE_RECOVER=0: ring overflow handled by the host-driven fallback only
   int mih_bcodes = -1;                        // VC_MIH_BCODES: -1 auto, 0 / 1 forced
+  int mih_bent = -1;                          // VC_MIH_BENT: id + code records in bucket order (32-bit substrings of 64-bit codes): -1 auto, 0 / 1
   int scan_small = 1;                         // VC_SCAN_SMALL=0: the general (LDS-streamed) query loop for every tile size
   uint64_t mih_budget = 0;                    // VC_MIH_BUDGET: probes per query run inside mih_query_kernel (0 = automatic)
   int resident_mb = -1;                       // VC_SCAN_RESIDENT_MB: database prefix kept in the Infinity Cache by the verify pass (-1 = default)

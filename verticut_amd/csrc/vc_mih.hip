@@ -46,6 +46,9 @@ struct VcTableView {
   // bucket through ids[] -> cols[] is an 8-byte gather per word that moves a 64-byte sector each; from the copy it is
   // a contiguous stream.  32-bit substrings keep gathering (0.02 items per bucket).
   const uint64_t* bcodes;
+  // Optional, 32-bit substrings of 64-bit codes (configs[1]): {id, 0, code} of the pos-th entry in ONE 16-byte record.
+  // Their buckets hold one entry, and ids[pos] -> cols[id] are two dependent 64-byte sectors per hit where this is one.
+  const uint4* bent;
   uint32_t n_unique;
   uint32_t pad;
 };
@@ -63,6 +66,15 @@ __global__ void __launch_bounds__(256) mih_bcodes_kernel(const uint64_t* __restr
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * W; e += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t j = e / n, pos = e - j * n;
     out[e] = cols[j * stride + ids[pos]];
+  }
+}
+
+__global__ void __launch_bounds__(256) mih_bent_kernel(const uint64_t* __restrict__ col0, const uint32_t* __restrict__ ids, uint64_t n,
+                                                       uint4* __restrict__ out) {
+  for (uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t id = ids[pos];
+    const uint64_t c = col0[id];
+    out[pos] = make_uint4(id, 0u, (uint32_t)c, (uint32_t)(c >> 32));
   }
 }
 
@@ -717,6 +729,12 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         meta[g] = s_meta[lo];
         const VcTableView& tv = s_tv[meta[g] & 0xFFu];
         const uint32_t pos = s_key[lo] + (ec - s_pref[lo]);
+        if (W == 1 && tv.bent) {
+          const uint4 rec = tv.bent[pos];
+          local[g] = rec.x;
+          x[g][0] = ((uint64_t)rec.w << 32) | rec.z;
+          continue;
+        }
         local[g] = tv.ids[pos];
         if (tv.bcodes) {
 #pragma unroll
@@ -1237,6 +1255,12 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
     if (want_bcodes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * W * 8 > free_b / 3) want_bcodes = false;
     if (knobs.mih_bcodes >= 0) want_bcodes = knobs.mih_bcodes != 0;   // dev knob VC_MIH_BCODES
   }
+  bool want_bent = sbits == 32 && W == 1;   // (VcTableView::bent; VC_MIH_BENT=0/1 overrides)
+  {
+    size_t free_b = 0, total_b = 0;
+    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 > free_b / 3) want_bent = false;
+    if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W == 1;
+  }
   const uint64_t nkeyspace = 1ull << sbits;
   const uint64_t bm_words = std::max<uint64_t>(nkeyspace / 32, 8);
   const uint32_t mask = sbits == 32 ? 0xFFFFFFFFu : (uint32_t)(nkeyspace - 1);
@@ -1323,6 +1347,14 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
       hipLaunchKernelGGL(mih_bcodes_kernel, dim3(grid_for(n * W, n_cu)), dim3(256), 0, s, d_cols, stride, W, ids, n, bc);
       B_CHECK(hipGetLastError());
       tv.bcodes = bc;
+    }
+    tv.bent = nullptr;
+    if (want_bent && n) {
+      uint4* be = nullptr;
+      B_CHECK(dalloc((void**)&be, (size_t)n * 16, true));
+      hipLaunchKernelGGL(mih_bent_kernel, dim3(grid_for(n, n_cu)), dim3(256), 0, s, d_cols, ids, n, be);
+      B_CHECK(hipGetLastError());
+      tv.bent = be;
     }
     ix->h_tables[t] = tv;
   }
@@ -1516,6 +1548,12 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
     if (want_bcodes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * W * 8 > free_b / 3) want_bcodes = false;
     if (knobs.mih_bcodes >= 0) want_bcodes = knobs.mih_bcodes != 0;
   }
+  bool want_bent = sbits == 32 && W == 1;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 > free_b / 3) want_bent = false;
+    if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W == 1;
+  }
   auto dalloc = [&](void** p, size_t bytes) -> int {
     hipError_t r = hipMalloc(p, std::max<size_t>(bytes, 256));
     if (r != hipSuccess) {
@@ -1548,6 +1586,12 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
       if ((rc = dalloc((void**)&bc, (size_t)n * W * 8))) break;
       hipLaunchKernelGGL(mih_bcodes_kernel, dim3(grid_for(n * W, n_cu)), dim3(256), 0, s, d_cols, stride, W, ids, n, bc);
       tv.bcodes = bc;
+    }
+    if (want_bent && n) {
+      uint4* be = nullptr;
+      if ((rc = dalloc((void**)&be, (size_t)n * 16))) break;
+      hipLaunchKernelGGL(mih_bent_kernel, dim3(grid_for(n, n_cu)), dim3(256), 0, s, d_cols, ids, n, be);
+      tv.bent = be;
     }
     ix->h_tables[t] = tv;
   }
