@@ -431,7 +431,11 @@ uint64_t vco_mih_radius(void* h, const uint8_t* query, uint32_t radius, uint32_t
                         uint64_t* n_probes) {
   MihOracle* o = static_cast<MihOracle*>(h);
   const uint32_t s_bits = o->nlb * 8;
-  const uint32_t rsub = std::min(s_bits, radius / o->m);
+  // Pigeonhole with multi-index hashing's sharper radii (this fixed-radius search has no counterpart function in the
+  // reference -- it is BASELINE configs[1] phrased with the reference's shell enumeration, search_worker.cc:222-264):
+  // R = m q + a  =>  tables 0..a search substring radius q, tables a+1..m-1 only q - 1; were every substring beyond
+  // its radius the distance would be at least (a+1)(q+1) + (m-a-1) q = R + 1.
+  const uint32_t rq = radius / o->m, ra = radius % o->m;
   if (threads < 1) threads = 1;
   if (threads > o->m) threads = o->m;
   std::vector<std::vector<uint64_t> > per_rank(o->m);
@@ -439,6 +443,8 @@ uint64_t vco_mih_radius(void* h, const uint8_t* query, uint32_t radius, uint32_t
   auto rank_work = [&](uint32_t t) {
     uint32_t start = binary_to_int((const char*)query + t * o->nlb, (int)o->nlb);
     if (o->key_mode == 1 && o->nlb < 4) start &= (1u << s_bits) - 1u;
+    if (t > ra && rq == 0) return;                                   // radius "-1": this table is not searched
+    const uint32_t rsub = std::min(s_bits, t <= ra ? rq : rq - 1);
     for (uint32_t r = 0; r <= rsub; ++r) {
       FindCtx c{o, query, false, t, 0, 0, &per_rank[t]};
       enumerate_entry(c, start, 0, (int)r);

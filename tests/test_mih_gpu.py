@@ -232,6 +232,31 @@ def test_radius_search(vc, oracle, bits, m, radius):
             assert np.array_equal(mih[i], exp)
 
 
+@pytest.mark.parametrize("bits,m", [(64, 2), (64, 4), (64, 8), (128, 4)])
+def test_radius_search_every_remainder_of_the_pigeonhole_split(vc, oracle, bits, m):
+    """Radius search gives table t the substring radius q (t <= a) or q - 1 (t > a) for R = m q + a -- the tables beyond
+    a are not searched at all while R < m.  Every R from 0 over a few multiples of m, items at EVERY distance around the
+    query (flips spread over the substrings on purpose), MIH == linear == numpy; both the query-kernel path and the
+    multi-block shell kernels (VC_MIH_HOST_LOOP=1 is covered by the host-loop test; here the budget decides)."""
+    n = 30000
+    rng = np.random.default_rng(bits + m)
+    base = oracle.gen_codes(1, bits, 5)[0]
+    codes = np.tile(base, (n, 1))
+    for i in range(n):                                  # 0..2m+3 flips at random positions: every split of R over the substrings
+        for b in rng.choice(bits, size=int(rng.integers(0, 2 * m + 4)), replace=False):
+            codes[i, b // 8] ^= np.uint8(1 << (b % 8))
+    q = base[None, :].copy()
+    d = oracle.np_distances(codes, q[0])
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        e.build_index()
+        for radius in range(0, 2 * m + 3):
+            ids = np.nonzero(d <= radius)[0]
+            exp = np.sort(oracle.pack(d[ids], ids.astype(np.uint64)))
+            mih = e.search_radius(q, radius, mode=vc.MODE_MIH_EXACT, cap_per_query=1 << 15)
+            assert np.array_equal(mih[0], exp), (radius, len(mih[0]), len(exp))
+
+
 def test_mih_needs_index_and_rejects_stale(vc):
     with vc.Engine(128, capacity=1000, n_tables=4) as e:
         e.add_synthetic(500, seed=1, kind=vc.SYNTH_CLUSTERED, n_centres=5, max_flips=2)

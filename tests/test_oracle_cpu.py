@@ -274,4 +274,6 @@ def test_oracle_threaded_find_and_radius_search(oracle):
                     ids = np.nonzero(d <= 8)[0]
                     assert np.array_equal(r, np.sort(oracle.pack(d[ids], ids.astype(np.uint64))))
                     import math
-                    assert probes == m * sum(math.comb(64 // m, j) for j in range(8 // m + 1))
+                    # R = m q + a: tables 0..a search substring radius q, the others q - 1
+                    q_, a_ = divmod(8, m)
+                    assert probes == sum(math.comb(64 // m, j) for t in range(m) for j in range((q_ if t <= a_ else q_ - 1) + 1))

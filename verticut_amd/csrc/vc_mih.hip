@@ -173,6 +173,7 @@ struct ProbeParams {
   MihState st;
   uint32_t r, nkeys, m, sbits, id_base, flags, cap, count_seen;
   uint64_t n;                // items in the index (stride of the bucket-order code copies)
+  uint32_t m_probe;          // tables probed by this launch: 0 .. m_probe-1 (0 = all m; radius search narrows the outer shells)
 };
 
 // lookup of bucket (t, key): start offset and length (0 = PROXY_NOT_FOUND)
@@ -542,7 +543,9 @@ struct QueryKernelParams {
   uint32_t mode;               // MQ_MODE_*
   uint32_t radius;             // MQ_MODE_RADIUS: full-distance radius
   uint32_t stop_mult;
-  uint32_t r_last;             // last shell run in here (radius mode: the substring radius)
+  uint32_t r_last;             // last shell run in here (radius mode: the substring radius of the first n_big tables)
+  uint32_t n_big;              // radius mode: tables 0 .. n_big-1 search shells 0 .. r_last,
+  uint32_t small_shells;       //              the others shells 0 .. small_shells-1 (0 = not at all)
   uint32_t buf_entries;        // LDS top-k + candidate buffer (power of two, >= k + MQ_ROUND)
   uint32_t* heavy_list;
   uint32_t* heavy_ctr;
@@ -815,15 +818,17 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   // ---- one shell (or the whole ball) of ALL tables, 32-bit substrings: granule scan over the segments in s_seg*.
   // The tables share one item space (item = table * per_table + pattern index), so the 1-, 26- and 326-granule shells
   // 0..2 of four tables are 1 + 1 + 2 passes, not 4 + 4 + 4: a pass costs a barrier and a memory round trip whatever it holds.
+  uint32_t tb_first = 0, tb_count = m;   // the tables a scan covers (radius mode narrows them, see below)
   auto scan32 = [&]() {
     const uint32_t per_table = s_segstart[s_nseg];
-    const uint32_t total = per_table * m;
+    const uint32_t total = per_table * tb_count;
     for (uint32_t base = 0; base < total; base += MQ_PASS32) {
       const uint32_t idx0 = base + tid * MQ_G32;
       uint32_t t = 0, rem = 0, seg = 0, hi = 0;
       if (idx0 < total) {
         t = idx0 / per_table;
         rem = idx0 - t * per_table;
+        t += tb_first;
         while (rem >= s_segstart[seg + 1]) ++seg;
         hi = mq_unrank(s_binom, rem - s_segstart[seg], s_segh[seg], MQ_HI);
       }
@@ -875,7 +880,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           c += __popc(w[g][4 * cc + 0]) + __popc(w[g][4 * cc + 1]) + __popc(w[g][4 * cc + 2]) + __popc(w[g][4 * cc + 3]);
         }
         cnt += c;
-        if ((meta0[g] & 0xFFu) == 0 && idx0 + g < per_table) cnt0 += c;
+        if ((meta0[g] & 0xFFu) == 0 && tb_first == 0 && idx0 + g < per_table) cnt0 += c;
       }
       if (p.flags & VC_FLAG_USE_BITMAP) {   // n_sub_reads_ of table 0 = its leaves whose bit is set (search_worker.cc:238-245)
         uint32_t wt;
@@ -913,13 +918,14 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   // ---- one shell of ALL tables, <= 16-bit substrings: direct offsets, keys by combination unranking + Gosper
   auto scan_direct = [&](uint32_t r) {
     const uint32_t nkeys = s_binom[s * MQ_BW + r];
-    const uint32_t total = nkeys * m;
+    const uint32_t total = nkeys * tb_count;
     for (uint32_t base = 0; base < total; base += MQ_PASS) {
       const uint32_t j0 = base + tid * MQ_G;
       uint32_t t = 0, rem = 0, mask = 0;
       if (j0 < total) {
         t = j0 / nkeys;
         rem = j0 - t * nkeys;
+        t += tb_first;
         mask = mq_unrank(s_binom, rem, r, s);
       }
       uint32_t offv[MQ_G], lenv[MQ_G], tt[MQ_G];
@@ -1005,16 +1011,32 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 
   const uint32_t S = s;            // loop bound radius <= n_local_bytes_ * 8 (search_worker.cc:170)
   if (!knn) {
-    // fixed-radius neighbour search: shells 0 .. r_last of every table, every item within the full distance kept
+    // fixed-radius neighbour search, every item within the full distance R kept.  Pigeonhole with the sharper radii of
+    // multi-index hashing: R = m q + a  =>  tables 0..a search substring radius q, tables a+1..m-1 only q - 1 (were every
+    // substring beyond its radius the distance would be >= (a+1)(q+1) + (m-a-1) q = R + 1).  The owner rule of the drain
+    // (lowest table among those with the smallest substring distance) needs no change: the radii do not increase with the
+    // table number, so the owner of an item within R always lies inside its own radius.  configs[1] (R = 8, m = 2: radii
+    // 4 and 3) probes 12 951 instead of 21 806 bitmap sectors per query.
+    const uint32_t n_big = min(p.n_big, m);
     if (s == 32) {
+      tb_first = 0; tb_count = n_big;
       plan32(p.r_last, true);
       scan32();
+      if (n_big < m && p.small_shells) {
+        tb_first = n_big; tb_count = m - n_big;
+        plan32(p.small_shells - 1, true);
+        scan32();
+      }
     } else {
-      for (uint32_t r = 0; r <= p.r_last; ++r) scan_direct(r);
+      for (uint32_t r = 0; r <= p.r_last; ++r) {
+        tb_first = 0; tb_count = r < p.small_shells ? m : n_big;
+        scan_direct(r);
+      }
     }
+    tb_first = 0; tb_count = m;
     if (s_nh) drain();
     __syncthreads();
-    for (uint32_t r = 0; r <= p.r_last; ++r) w_probes += (unsigned long long)m * c_binom[s][r];
+    for (uint32_t r = 0; r <= p.r_last; ++r) w_probes += (unsigned long long)(r < p.small_shells ? m : n_big) * c_binom[s][r];
     put_work();
     if (!spilled) {
       merge();                                       // sorts the LDS results (kk = their number)
@@ -1693,7 +1715,7 @@ static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, bool with_ring,
 }
 
 static hipError_t launch_probe(const ProbeParams& p, uint32_t W, uint32_t n_list, hipStream_t s) {
-  const dim3 grid((p.nkeys + MIH_PCH - 1) / MIH_PCH, p.m, n_list);
+  const dim3 grid((p.nkeys + MIH_PCH - 1) / MIH_PCH, p.m_probe ? p.m_probe : p.m, n_list);
   switch (W) {
     case 1: hipLaunchKernelGGL(mih_probe_kernel<1>, grid, dim3(MIH_BLK), 0, s, p); break;
     case 2: hipLaunchKernelGGL(mih_probe_kernel<2>, grid, dim3(MIH_BLK), 0, s, p); break;
@@ -1955,12 +1977,17 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
   if (use_mih && (rc = upload_binom(err))) return rc;
   const uint32_t bits = W * 64;
   if (radius > bits) radius = bits;
-  // pigeonhole: dist <= R implies some substring within floor(R/m) (search_R_neighbors shells, search_worker.cc:222-227)
-  const uint32_t rsub = use_mih ? std::min(ix->sbits, radius / ix->m) : 0;
+  // pigeonhole (search_R_neighbors shells, search_worker.cc:222-227) with multi-index hashing's sharper radii:
+  // R = m q + a  =>  tables 0..a search substring radius q (n_big of them), the others q - 1 (small_shells shells)
+  const uint32_t rq = use_mih ? radius / ix->m : 0, ra = use_mih ? radius % ix->m : 0;
+  const uint32_t rsub = use_mih ? std::min(ix->sbits, rq) : 0;
+  const uint32_t n_big = use_mih ? std::min(ix->m, ra + 1) : 0;
+  const uint32_t small_shells = (use_mih && rq) ? std::min(ix->sbits, rq - 1) + 1 : 0;
+  auto tables_at = [&](uint32_t r) { return r < small_shells ? ix->m : n_big; };
   bool inblock = false;
   if (use_mih && ix->knobs.mih_host_loop == 0) {
     uint64_t probes = 0;
-    for (uint32_t r = 0; r <= rsub; ++r) probes += (uint64_t)ix->m * binom_host(ix->sbits, r);
+    for (uint32_t r = 0; r <= rsub; ++r) probes += (uint64_t)tables_at(r) * binom_host(ix->sbits, r);
     const double avg_bucket = (double)ix->n / (ix->sbits >= 32 ? 4294967296.0 : (double)(1ull << ix->sbits));
     inblock = probes <= MQ_RADIUS_BUDGET && rsub <= 16 && (double)probes * avg_bucket <= MQ_ENTRY_BUDGET;
   }
@@ -2012,7 +2039,8 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
           QueryKernelParams qp{};
           qp.cols = d_cols; qp.stride = stride; qp.n = ix->n; qp.tables = ix->d_tables; qp.queries = d_q + (size_t)q0 * W;
           qp.st = st; qp.m = ix->m; qp.sbits = ix->sbits; qp.id_base = id_base; qp.flags = ix->flags; qp.cap = cap; qp.k = 0;
-          qp.mode = MQ_MODE_RADIUS; qp.radius = radius; qp.r_last = rsub; qp.buf_entries = 2048;
+          qp.mode = MQ_MODE_RADIUS; qp.radius = radius; qp.r_last = rsub; qp.n_big = n_big; qp.small_shells = small_shells;
+          qp.buf_entries = 2048;
           R_CHECK(timed_query_launch(ix, qp, W, qt, s));
           sorted_flag = d_sorted;
         } else {
@@ -2023,7 +2051,7 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
             ProbeParams p{};
             p.cols = d_cols; p.stride = stride; p.tables = ix->d_tables; p.queries = d_q + (size_t)q0 * W; p.list = list;
             p.st = st; p.r = r; p.nkeys = binom_host(ix->sbits, r); p.m = ix->m; p.sbits = ix->sbits; p.id_base = id_base;
-            p.flags = ix->flags; p.cap = cap; p.count_seen = 1; p.n = ix->n;
+            p.flags = ix->flags; p.cap = cap; p.count_seen = 1; p.n = ix->n; p.m_probe = tables_at(r);
             R_CHECK(launch_probe(p, W, qt, s));
           }
         }
