@@ -150,7 +150,7 @@ def cpu_baseline_mih(args, m, kind, radius=None, clustered=False):
         "sample": "%d queries in %.1f s on a %d-code sample of the same synthetic DB (index build %.1f s not counted), %d threads "
                   "= one per table; %s; NOT scaled to the full size (bucket sizes grow with N, probes per query do not: %.0f "
                   "bucket gets per query)" % (done, dt, sample_n, t_build, threads,
-                                              "search_R_neighbors shells 0..r/m + gather + dedup (search_worker.cc:222-264)"
+                                              "search_R_neighbors shells 0..q per table, q = r/m for the first r mod m + 1 tables and r/m - 1 for the rest, + gather + dedup (search_worker.cc:222-264)"
                                               if kind == "radius" else "SearchWorker::find exact loop (search_worker.cc:159-218)",
                                               probes / max(done, 1)),
     }
