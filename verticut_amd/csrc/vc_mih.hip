@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 
 // =============================================================================================================
 // mih_query_kernel -- ONE 256-thread block runs a query's whole radius loop (search_worker.cc:159-218 / 93-157,
-// shells 0..r_last) or a whole fixed-radius neighbour search (search_R_neighbors shells 0..R/m, :222-227) in ONE
+// shells 0..r_last) or a whole fixed-radius neighbour search (search_R_neighbors shells of every table up to its pigeonhole radius, :222-227) in ONE
 // launch: probe -> bucket lookup -> verify -> top-k merge -> stop rule, shell after shell, with no host round trip
 // and no kernel boundary between shells.  Queries are independent, so the grid is simply one block per query; what
 // the round-1 loop paid per shell (memset + probe + select + commit + an 8-byte read-back and ~20 us of host
