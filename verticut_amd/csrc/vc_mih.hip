@@ -50,8 +50,8 @@ struct VcTableView {
   // bucket through ids[] -> cols[] is an 8-byte gather per word that moves a 64-byte sector each; from the copy it is
   // a contiguous stream.  32-bit substrings keep gathering (0.02 items per bucket).
   const uint64_t* bcodes;
-  // Optional, 32-bit substrings of 64-bit codes (configs[1]): {id, 0, code} of the pos-th entry in ONE 16-byte record.
-  // Their buckets hold one entry, and ids[pos] -> cols[id] are two dependent 64-byte sectors per hit where this is one.
+  // Optional, 32-bit substrings of 64- / 128-bit codes: {id, 0, code} of the pos-th entry in ONE 16- / 32-byte record.
+  // Their buckets hold one entry, and ids[pos] -> cols[id] are two (three) dependent sectors per hit where this is one.
   const uint4* bent;
   uint32_t n_unique;
   uint32_t pad;
@@ -73,12 +73,18 @@ __global__ void __launch_bounds__(256) mih_bcodes_kernel(const uint64_t* __restr
   }
 }
 
-__global__ void __launch_bounds__(256) mih_bent_kernel(const uint64_t* __restrict__ col0, const uint32_t* __restrict__ ids, uint64_t n,
-                                                       uint4* __restrict__ out) {
+__global__ void __launch_bounds__(256) mih_bent_kernel(const uint64_t* __restrict__ cols, uint64_t stride, uint32_t W,
+                                                       const uint32_t* __restrict__ ids, uint64_t n, uint4* __restrict__ out) {
   for (uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t id = ids[pos];
-    const uint64_t c = col0[id];
-    out[pos] = make_uint4(id, 0u, (uint32_t)c, (uint32_t)(c >> 32));
+    const uint64_t c0 = cols[id];
+    if (W == 1) {
+      out[pos] = make_uint4(id, 0u, (uint32_t)c0, (uint32_t)(c0 >> 32));
+    } else {   // W == 2: 32 bytes per entry, half a sector
+      const uint64_t c1 = cols[stride + id];
+      out[2 * pos] = make_uint4(id, 0u, (uint32_t)c0, (uint32_t)(c0 >> 32));
+      out[2 * pos + 1] = make_uint4((uint32_t)c1, (uint32_t)(c1 >> 32), 0u, 0u);
+    }
   }
 }
 
@@ -760,10 +766,14 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         meta[g] = s_meta[lo];
         const VcTableView& tv = s_tv[meta[g] & 0xFFu];
         const uint32_t pos = s_key[lo] + (ec - s_pref[lo]);
-        if (W == 1 && tv.bent) {
-          const uint4 rec = tv.bent[pos];
+        if (W <= 2 && tv.bent) {
+          const uint4 rec = tv.bent[(uint64_t)pos * W];
           local[g] = rec.x;
           x[g][0] = ((uint64_t)rec.w << 32) | rec.z;
+          if (W == 2) {
+            const uint4 rec1 = tv.bent[(uint64_t)pos * 2 + 1];
+            x[g][W - 1] = ((uint64_t)rec1.y << 32) | rec1.x;
+          }
           continue;
         }
         local[g] = tv.ids[pos];
@@ -1305,11 +1315,11 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
     if (want_bcodes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * W * 8 > free_b / 3) want_bcodes = false;
     if (knobs.mih_bcodes >= 0) want_bcodes = knobs.mih_bcodes != 0;   // dev knob VC_MIH_BCODES
   }
-  bool want_bent = sbits == 32 && W == 1;   // (VcTableView::bent; VC_MIH_BENT=0/1 overrides)
+  bool want_bent = sbits == 32 && W <= 2;   // (VcTableView::bent; VC_MIH_BENT=0/1 overrides)
   {
     size_t free_b = 0, total_b = 0;
-    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 > free_b / 3) want_bent = false;
-    if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W == 1;
+    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 * W > free_b / 3) want_bent = false;
+    if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W <= 2;
   }
   const uint64_t nkeyspace = 1ull << sbits;
   const uint64_t bm_words = std::max<uint64_t>(nkeyspace / 32, 8);
@@ -1406,8 +1416,8 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
     tv.bent = nullptr;
     if (want_bent && n) {
       uint4* be = nullptr;
-      B_CHECK(dalloc((void**)&be, (size_t)n * 16, true));
-      hipLaunchKernelGGL(mih_bent_kernel, dim3(grid_for(n, n_cu)), dim3(256), 0, s, d_cols, ids, n, be);
+      B_CHECK(dalloc((void**)&be, (size_t)n * 16 * W, true));
+      hipLaunchKernelGGL(mih_bent_kernel, dim3(grid_for(n, n_cu)), dim3(256), 0, s, d_cols, stride, W, ids, n, be);
       B_CHECK(hipGetLastError());
       tv.bent = be;
     }
@@ -1603,11 +1613,11 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
     if (want_bcodes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * W * 8 > free_b / 3) want_bcodes = false;
     if (knobs.mih_bcodes >= 0) want_bcodes = knobs.mih_bcodes != 0;
   }
-  bool want_bent = sbits == 32 && W == 1;
+  bool want_bent = sbits == 32 && W <= 2;
   {
     size_t free_b = 0, total_b = 0;
-    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 > free_b / 3) want_bent = false;
-    if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W == 1;
+    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 * W > free_b / 3) want_bent = false;
+    if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W <= 2;
   }
   auto dalloc = [&](void** p, size_t bytes) -> int {
     hipError_t r = hipMalloc(p, std::max<size_t>(bytes, 256));
@@ -1650,8 +1660,8 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
     }
     if (want_bent && n) {
       uint4* be = nullptr;
-      if ((rc = dalloc((void**)&be, (size_t)n * 16))) break;
-      hipLaunchKernelGGL(mih_bent_kernel, dim3(grid_for(n, n_cu)), dim3(256), 0, s, d_cols, ids, n, be);
+      if ((rc = dalloc((void**)&be, (size_t)n * 16 * W))) break;
+      hipLaunchKernelGGL(mih_bent_kernel, dim3(grid_for(n, n_cu)), dim3(256), 0, s, d_cols, stride, W, ids, n, be);
       tv.bent = be;
     }
     ix->h_tables[t] = tv;
