@@ -2119,9 +2119,11 @@ int vc_radius_search(VcMihIndex* ix, bool use_mih, const uint64_t* d_cols, uint6
   if (use_mih) {
     // a radius whose substring shells cost more probes than scanning the shard costs distance evaluations is answered
     // by the scan (identical results; search_R_neighbors would enumerate up to 2^s keys per table, search_worker.cc:222-264)
-    const uint32_t rsub = std::min(ix->sbits, std::min(radius, W * 64) / ix->m);
+    const uint32_t rr = std::min(radius, W * 64), rq = rr / ix->m, ra = rr % ix->m;   // radii q (tables 0..a) and q - 1, as below
+    const uint32_t rsub = std::min(ix->sbits, rq), n_big = std::min(ix->m, ra + 1);
+    const uint32_t small_shells = rq ? std::min(ix->sbits, rq - 1) + 1 : 0;
     double probes = 0;
-    for (uint32_t r = 0; r <= rsub; ++r) probes += (double)ix->m * binom_host(ix->sbits, r);
+    for (uint32_t r = 0; r <= rsub; ++r) probes += (double)(r < small_shells ? ix->m : n_big) * binom_host(ix->sbits, r);
     if (probes > (double)std::max<uint64_t>(n, 1u << 20)) use_mih = false;
   }
   const uint32_t TQ = use_mih ? MIH_RADIUS_TILE : 64u;
