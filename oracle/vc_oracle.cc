@@ -26,7 +26,10 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <string>
 #include <thread>
@@ -263,6 +266,137 @@ uint32_t vco_linear_knn_mt(const uint8_t* codes, uint64_t n, uint32_t nbytes, co
   uint32_t c = (uint32_t)std::min<size_t>(all.size(), k);
   if (c) memcpy(out, all.data(), c * sizeof(uint64_t));
   return c;
+}
+
+
+// ---------------------------------------------------------------------------
+// Persistent worker pool for the big-database legs of the test suite and the all-cores CPU baseline of bench.py
+// (threads are created once; a job is a function of the worker index).  Plain test scaffolding: nothing in the
+// reference corresponds to it (its processes are MPI ranks, run_distributed_search.py:74).
+// ---------------------------------------------------------------------------
+struct VcoPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::function<void(uint32_t)> job;
+  uint64_t gen = 0;
+  uint32_t pending = 0;
+  bool stop = false;
+  explicit VcoPool(uint32_t n) {
+    for (uint32_t w = 0; w < n; ++w)
+      th.emplace_back([this, w]() {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(uint32_t)> f;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_job.wait(lk, [&]() { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            f = job;
+          }
+          f(w);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_all();
+          }
+        }
+      });
+  }
+  void run(const std::function<void(uint32_t)>& f) {
+    std::unique_lock<std::mutex> lk(mu);
+    job = f;
+    pending = (uint32_t)th.size();
+    ++gen;
+    cv_job.notify_all();
+    cv_done.wait(lk, [&]() { return pending == 0; });
+  }
+  ~VcoPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_job.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+
+void* vco_pool_create(uint32_t threads) { return new VcoPool(threads < 1 ? 1 : threads); }
+void vco_pool_destroy(void* p) { delete static_cast<VcoPool*>(p); }
+uint32_t vco_pool_size(void* p) { return (uint32_t)static_cast<VcoPool*>(p)->th.size(); }
+
+// vco_gen_codes over the workers of a pool (same definition, ids split into contiguous ranges)
+void vco_gen_codes_pool(void* pool, uint8_t* out, uint64_t first_id, uint64_t n, uint32_t bits, uint64_t seed,
+                        uint32_t kind, uint32_t n_centres, uint32_t max_flips) {
+  VcoPool* P = static_cast<VcoPool*>(pool);
+  const uint32_t T = (uint32_t)P->th.size();
+  P->run([=](uint32_t w) {
+    const uint64_t lo = n * w / T, hi = n * (w + 1) / T;
+    vco_gen_codes(out + lo * (bits / 8), first_id + lo, hi - lo, bits, seed, kind, n_centres, max_flips);
+  });
+}
+
+// a8 for a BATCH of queries over one slab of the database: linear_search.cc:39-64 (scan ids in order, max-heap of k
+// with strict-greater replace on the canonical packed value, as linear_canonical_range) -- every worker scans its id
+// range once for all nq queries, the per-range heaps are merged per query.  out [nq][k] ascending (padded with ~0),
+// counts [nq].  id_base = global id of the slab's first record.
+void vco_linear_knn_pool(void* pool, const uint8_t* codes, uint64_t n, uint32_t nbytes, const uint8_t* queries, uint32_t nq,
+                         uint32_t k, uint32_t id_base, uint64_t* out, uint32_t* counts) {
+  VcoPool* P = static_cast<VcoPool*>(pool);
+  const uint32_t T = (uint32_t)P->th.size();
+  std::vector<std::vector<std::vector<uint64_t> > > parts(T, std::vector<std::vector<uint64_t> >(nq));
+  P->run([&](uint32_t w) {
+    const uint64_t lo = n * w / T, hi = n * (w + 1) / T;
+    std::vector<std::priority_queue<uint64_t> > h(nq);
+    for (uint64_t i = lo; i < hi; ++i) {
+      const uint8_t* c = codes + i * nbytes;
+      for (uint32_t q = 0; q < nq; ++q) {
+        const uint64_t v = pack((uint32_t)hamming32(c, queries + (size_t)q * nbytes, nbytes), id_base + (uint32_t)i);
+        if (h[q].size() < k) h[q].push(v);
+        else if (h[q].top() > v) { h[q].pop(); h[q].push(v); }
+      }
+    }
+    for (uint32_t q = 0; q < nq; ++q) {
+      parts[w][q].resize(h[q].size());
+      for (size_t j = h[q].size(); j-- > 0;) { parts[w][q][j] = h[q].top(); h[q].pop(); }
+    }
+  });
+  for (uint32_t q = 0; q < nq; ++q) {
+    std::vector<uint64_t> all;
+    for (uint32_t w = 0; w < T; ++w) all.insert(all.end(), parts[w][q].begin(), parts[w][q].end());
+    std::sort(all.begin(), all.end());
+    const uint32_t c = (uint32_t)std::min<size_t>(all.size(), k);
+    for (uint32_t j = 0; j < k; ++j) out[(size_t)q * k + j] = j < c ? all[j] : ~0ull;
+    counts[q] = c;
+  }
+}
+
+// Brute-force fixed-radius search over one slab for a batch of queries: every item whose compute_hamming_dist
+// (image_tools.h:21-33) to the query is <= radius, packed dist<<32|id ascending -- the truth the MIH radius search
+// (search_R_neighbors shells + dedup, search_worker.cc:222-264) must reproduce.  out [nq][cap]; counts[q] = number
+// found (may exceed cap: then only the first cap in scan order per worker were kept and the caller retries).
+void vco_linear_radius_pool(void* pool, const uint8_t* codes, uint64_t n, uint32_t nbytes, const uint8_t* queries, uint32_t nq,
+                            uint32_t radius, uint32_t id_base, uint64_t* out, uint64_t cap, uint64_t* counts) {
+  VcoPool* P = static_cast<VcoPool*>(pool);
+  const uint32_t T = (uint32_t)P->th.size();
+  std::vector<std::vector<std::vector<uint64_t> > > parts(T, std::vector<std::vector<uint64_t> >(nq));
+  P->run([&](uint32_t w) {
+    const uint64_t lo = n * w / T, hi = n * (w + 1) / T;
+    for (uint64_t i = lo; i < hi; ++i) {
+      const uint8_t* c = codes + i * nbytes;
+      for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t d = (uint32_t)hamming32(c, queries + (size_t)q * nbytes, nbytes);
+        if (d <= radius) parts[w][q].push_back(pack(d, id_base + (uint32_t)i));
+      }
+    }
+  });
+  for (uint32_t q = 0; q < nq; ++q) {
+    std::vector<uint64_t> all;
+    for (uint32_t w = 0; w < T; ++w) all.insert(all.end(), parts[w][q].begin(), parts[w][q].end());
+    std::sort(all.begin(), all.end());
+    counts[q] = all.size();
+    for (uint64_t j = 0; j < all.size() && j < cap; ++j) out[(size_t)q * cap + j] = all[j];
+  }
 }
 
 // ----------------------------- MIH oracle ---------------------------------

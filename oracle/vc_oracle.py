@@ -61,6 +61,17 @@ def lib():
             f.argtypes = [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint32, C.c_uint32, u8p]
         L.vco_linear_knn_mt.restype = C.c_uint32
         L.vco_linear_knn_mt.argtypes = [u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
+        L.vco_pool_create.restype = C.c_void_p
+        L.vco_pool_create.argtypes = [C.c_uint32]
+        L.vco_pool_destroy.argtypes = [C.c_void_p]
+        L.vco_pool_size.restype = C.c_uint32
+        L.vco_pool_size.argtypes = [C.c_void_p]
+        L.vco_gen_codes_pool.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
+                                         C.c_uint32, C.c_uint32]
+        L.vco_linear_knn_pool.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          u8p, u8p]
+        L.vco_linear_radius_pool.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             u8p, C.c_uint64, u8p]
         L.vco_mih_create.restype = C.c_void_p
         L.vco_mih_create.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.vco_mih_destroy.argtypes = [C.c_void_p]
@@ -150,6 +161,94 @@ def linear_knn(codes, query, k, id_base=0, threads=1):
     else:
         c = lib().vco_linear_knn(_p(codes), codes.shape[0], codes.shape[1], _p(query), k, id_base, _p(out))
     return out[:c].copy()
+
+
+# ------------------------------------------------------------------ big databases: a persistent worker pool
+def host_threads():
+    """threads this process may really use (the GPU box reports 256 cores but a job owns a share of them)"""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+class Pool:
+    """Worker threads created once (oracle/vc_oracle.cc VcoPool): the full-size parity tests and bench.py's all-cores
+    CPU baseline run the linear_search.cc scan through it, slab by slab."""
+
+    def __init__(self, threads=None):
+        self.h = lib().vco_pool_create(threads or host_threads())
+        self.threads = lib().vco_pool_size(self.h)
+
+    def close(self):
+        if self.h:
+            lib().vco_pool_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def gen_codes(self, n, bits, seed, kind=0, n_centres=0, max_flips=0, first_id=0, out=None):
+        if out is None:
+            out = np.empty((n, bits // 8), dtype=np.uint8)
+        lib().vco_gen_codes_pool(self.h, _p(out), first_id, n, bits, seed, kind, n_centres, max_flips)
+        return out[:n]
+
+    def linear_knn(self, codes, queries, k, id_base=0):
+        """canonical top-k (ascending packed, padded with ~0) of every query over one slab: ([nq, k], counts[nq])"""
+        codes, queries = _bytes(codes), _bytes(queries)
+        nq = queries.shape[0]
+        out = np.empty((nq, k), dtype=np.uint64)
+        cnt = np.empty(nq, dtype=np.uint32)
+        lib().vco_linear_knn_pool(self.h, _p(codes), codes.shape[0], codes.shape[1], _p(queries), nq, k, id_base, _p(out), _p(cnt))
+        return out, cnt
+
+    def linear_radius(self, codes, queries, radius, id_base=0, cap=4096):
+        """every item within `radius` of every query over one slab: list of ascending packed arrays"""
+        codes, queries = _bytes(codes), _bytes(queries)
+        nq = queries.shape[0]
+        while True:
+            out = np.empty((nq, cap), dtype=np.uint64)
+            cnt = np.empty(nq, dtype=np.uint64)
+            lib().vco_linear_radius_pool(self.h, _p(codes), codes.shape[0], codes.shape[1], _p(queries), nq, radius, id_base,
+                                         _p(out), cap, _p(cnt))
+            if int(cnt.max(initial=0)) <= cap:
+                return [out[i, : int(cnt[i])].copy() for i in range(nq)]
+            cap = int(cnt.max())
+
+
+def slabs(n, slab):
+    """[lo, hi) ranges covering 0..n"""
+    return [(lo, min(lo + slab, n)) for lo in range(0, n, slab)]
+
+
+def linear_knn_slabbed(pool, n, bits, seed, queries, k, slab=1 << 27, kind=0, n_centres=0, max_flips=0):
+    """linear_search.cc:39-64 over the synthetic database of `n` codes WITHOUT holding it: generated slab by slab
+    (same definition as the device generator), scanned for all queries, per-slab top-k merged.  [nq, k] ascending."""
+    queries = _bytes(queries)
+    best = None
+    buf = np.empty((min(slab, n), bits // 8), dtype=np.uint8)
+    for lo, hi in slabs(n, slab):
+        codes = pool.gen_codes(hi - lo, bits, seed, kind, n_centres, max_flips, first_id=lo, out=buf)
+        part, _ = pool.linear_knn(codes, queries, k, id_base=lo)
+        best = part if best is None else np.sort(np.concatenate([best, part], axis=1), axis=1)[:, :k]
+    return best
+
+
+def linear_radius_slabbed(pool, n, bits, seed, queries, radius, slab=1 << 27):
+    queries = _bytes(queries)
+    res = [np.empty(0, dtype=np.uint64) for _ in range(queries.shape[0])]
+    buf = np.empty((min(slab, n), bits // 8), dtype=np.uint8)
+    for lo, hi in slabs(n, slab):
+        codes = pool.gen_codes(hi - lo, bits, seed, first_id=lo, out=buf)
+        part = pool.linear_radius(codes, queries, radius, id_base=lo)
+        res = [np.concatenate([a, b]) for a, b in zip(res, part)]     # slabs ascend in id, rows are sorted by (dist, id)
+    return [np.sort(r) for r in res]
 
 
 # ------------------------------------------------------------------ MIH

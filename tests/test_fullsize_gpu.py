@@ -1,5 +1,7 @@
-"""BASELINE.json shapes at FULL size on one MI355X, checked through size-independent properties (the oracle
-cannot scan 1e9 codes in test time): planted neighbours are found at their exact distance, every reported
+"""BASELINE.json shapes at FULL size on one MI355X.  Checked against the CPU oracle itself -- the database is
+regenerated on the host slab by slab from the shared generator definition and scanned by the oracle's
+linear_search.cc restatement on a worker pool (exact packed rows for a subset of the queries) -- and through
+size-independent properties for the rest: planted neighbours are found at their exact distance, every reported
 distance is recomputed from the stored code, results are ascending and reproducible, independent GPU paths
 agree (MIH == linear scan; one engine == two half-database engines + merge; query tile 1 == query tile 8)."""
 import numpy as np
@@ -26,20 +28,28 @@ def _check_rows(e, q, rows, counts):
             assert int(np.unpackbits(code ^ q[i]).sum()) == int(r[j] >> SH)
 
 
-def test_config3_top100_over_1e9_codes_128bit(vc):
+def test_config3_top100_over_1e9_codes_128bit(vc, oracle):
     n, bits, k = 1_000_000_000, 128, 100
     rng = np.random.default_rng(3)
     with vc.Engine(bits, capacity=n, query_tile=8) as e:
         e.add_synthetic(n, seed=34)
-        plant = [int(x) for x in rng.integers(0, n, size=8)]
-        nflip = [0, 1, 2, 3, 5, 8, 13, 21]
-        q = np.stack([_flip(e.get_code(g), rng.choice(bits, size=f, replace=False), rng) for g, f in zip(plant, nflip)])
+        plant = [int(x) for x in rng.integers(0, n, size=6)]
+        nflip = [0, 1, 3, 8, 13, 21]
+        q = np.stack([_flip(e.get_code(g), rng.choice(bits, size=f, replace=False), rng) for g, f in zip(plant, nflip)]
+                     + [rng.integers(0, 256, size=bits // 8, dtype=np.uint8) for _ in range(2)])   # + two with no planted neighbour
         rows, cnt = e.search_knn(q, k)
         assert np.all(cnt == k)
         for i, (g, f) in enumerate(zip(plant, nflip)):      # the planted item is the nearest neighbour, at f bits
             assert int(rows[i, 0] & MASK) == g and int(rows[i, 0] >> SH) == f
             assert int(rows[i, 1] >> SH) > 21               # uniform 128-bit codes: everything else is far away
         _check_rows(e, q, rows, cnt)
+        # the oracle over the SAME 1e9 codes (linear_search.cc:39-64 restated; the database regenerated on the host slab
+        # by slab): exact packed rows of two planted and the two uniform queries -- a true neighbour dropped anywhere in
+        # the 16 GB would show here
+        sel = [1, 4, 6, 7]
+        with oracle.Pool() as pool:
+            exp = oracle.linear_knn_slabbed(pool, n, bits, 34, q[sel], k)
+        assert np.array_equal(rows[sel], exp)
         again, _ = e.search_knn(q, k)                       # reproducible despite racing threshold updates
         assert np.array_equal(rows, again)
         one_by_one = np.stack([e.search_knn(q[i:i + 1], k)[0][0] for i in range(2)])   # tile of 1 == tile of 8
@@ -67,7 +77,7 @@ def test_config3_top100_over_1e9_codes_128bit(vc):
         eh.close()
 
 
-def test_config2_radius8_mih_over_1e8_codes_64bit(vc):
+def test_config2_radius8_mih_over_1e8_codes_64bit(vc, oracle):
     n, bits, m, radius = 100_000_000, 64, 2, 8
     rng = np.random.default_rng(2)
     with vc.Engine(bits, capacity=n, n_tables=m) as e:
@@ -75,13 +85,22 @@ def test_config2_radius8_mih_over_1e8_codes_64bit(vc):
         e.build_index()
         plant = [int(x) for x in rng.integers(0, n, size=16)]
         nflip = [int(x) for x in rng.integers(0, radius + 1, size=16)]
-        q = np.stack([_flip(e.get_code(g), rng.choice(bits, size=f, replace=False), rng) for g, f in zip(plant, nflip)])
+        q = np.stack([_flip(e.get_code(g), rng.choice(bits, size=f, replace=False), rng) for g, f in zip(plant, nflip)]
+                     + [rng.integers(0, 256, size=bits // 8, dtype=np.uint8)])      # + one with (almost surely) no neighbour
         mih = e.search_radius(q, radius, mode=vc.MODE_MIH_EXACT)
         lin = e.search_radius(q, radius, mode=vc.MODE_LINEAR)
         for i, (g, f) in enumerate(zip(plant, nflip)):
             assert np.array_equal(mih[i], lin[i])            # hash-probe path == full scan
             assert (np.uint64(f) << SH) | np.uint64(g) in mih[i]
             assert np.all((mih[i] >> SH) <= radius) and np.all(mih[i][1:] > mih[i][:-1])
+        assert np.array_equal(mih[16], lin[16])
+        # the oracle's brute force over the SAME 1e8 codes (compute_hamming_dist of every record, image_tools.h:21-33):
+        # "all within 8" of six of the queries equals both the MIH and the scan result
+        sel = [0, 3, 7, 11, 15, 16]
+        with oracle.Pool() as pool:
+            exp = oracle.linear_radius_slabbed(pool, n, bits, 34, q[sel], radius)
+        for j, i in enumerate(sel):
+            assert np.array_equal(mih[i], exp[j]) and np.array_equal(lin[i], exp[j])
         # exact k-NN through MIH agrees with the scan on the distances (ties at the k-th distance may differ)
         got, cnt, st = e.search_knn(q[:4], 3, mode=vc.MODE_MIH_EXACT, with_stats=True)
         ref, _ = e.search_knn(q[:4], 3, mode=vc.MODE_LINEAR)
@@ -164,3 +183,43 @@ def test_config5_per_gpu_share_5e8_codes_4096_queries(vc):
         e8.add_synthetic(n, seed=34)
         r8, c8 = e8.search_knn(q[sub], k)
         assert np.array_equal(r8, rows[sub]) and np.all(c8 == k)
+
+
+def test_mih_exact_top100_over_1e9_clustered_codes_128bit(vc, oracle):
+    """The metric's size through the north star's engine: SearchWorker::find (search_worker.cc:159-218) exact top-100 by
+    multi-index hashing over 1e9 clustered 128-bit codes, m = 4 tables of 32-bit substrings (34 GB of index next to the
+    16 GB of codes; the {id, code} record copies do not fit a third of the memory here, so entries are gathered through
+    ids[] -> code columns).  Distances against the oracle's linear scan of the same 1e9 codes for four queries, against
+    the HIP scan for all, ids below the k-th distance identical, statistics equal to the replayed stop rule."""
+    n, bits, k, m = 1_000_000_000, 128, 100, 4
+    nc, mf = n // 1000, 11
+    rng = np.random.default_rng(9)
+    nq = 64
+    with vc.Engine(bits, capacity=n, n_tables=m, query_tile=8) as e:
+        e.add_synthetic(n, seed=34, kind=vc.SYNTH_CLUSTERED, n_centres=nc, max_flips=mf)
+        e.build_index()
+        plant = [int(x) for x in rng.integers(0, n, size=nq)]
+        nflip = [int(x) for x in rng.integers(0, 5, size=nq)]
+        q = np.stack([_flip(e.get_code(g), rng.choice(bits, size=f, replace=False), rng) for g, f in zip(plant, nflip)])
+        got, cnt, st = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        lin, lcnt = e.search_knn(q, k, mode=vc.MODE_LINEAR)
+        assert np.all(cnt == k) and np.all(lcnt == k)
+        shell = [1, 32, 496, 4960, 35960, 201376, 906192, 3365856, 10518300]        # C(32, r)
+        for i in range(nq):
+            assert np.array_equal(got[i] >> SH, lin[i] >> SH)                       # same distance multiset as the scan
+            D = int(got[i, -1] >> SH)
+            below = got[i][(got[i] >> SH) < np.uint64(D)]
+            assert np.array_equal(below, lin[i][: len(below)])                      # identical below the k-th distance
+            pk = (np.uint64(nflip[i]) << SH) | np.uint64(plant[i])
+            assert pk in got[i] or pk > got[i, -1]                                  # the planted item, unless k nearer ones exist
+            # stop rule replayed (search_worker.cc:201-205): shell floor(D/4), or one earlier when D is a multiple of 4
+            r0 = D // 4
+            assert st[i].radius in ((r0 - 1, r0) if D % 4 == 0 and D else (r0,))
+            assert st[i].n_sub_reads == sum(shell[: st[i].radius + 1]) and st[i].n_local_reads == 0
+            assert st[i].n_candidates >= k
+        _check_rows(e, q[:6], got[:6], cnt[:6])
+        sel = [0, 1, 2, 3]
+        with oracle.Pool() as pool:
+            exp = oracle.linear_knn_slabbed(pool, n, bits, 34, q[sel], k, kind=1, n_centres=nc, max_flips=mf)
+        assert np.array_equal(lin[sel], exp)                                        # the HIP scan IS the oracle's row
+        assert np.array_equal(got[sel] >> SH, exp >> SH)

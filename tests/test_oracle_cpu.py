@@ -277,3 +277,33 @@ def test_oracle_threaded_find_and_radius_search(oracle):
                     # R = m q + a: tables 0..a search substring radius q, the others q - 1
                     q_, a_ = divmod(8, m)
                     assert probes == sum(math.comb(64 // m, j) for t in range(m) for j in range((q_ if t <= a_ else q_ - 1) + 1))
+
+
+def test_pool_helpers_equal_the_single_thread_oracle(oracle):
+    """the worker-pool legs used at full size (slabbed generation + batched linear_search.cc scan + brute-force radius
+    search) are the single-thread oracle, slab boundaries and worker ranges included"""
+    n = 200_003
+    rng = np.random.default_rng(1)
+    with oracle.Pool(5) as P:
+        for kw in ({}, {"kind": 1, "n_centres": 50, "max_flips": 9}):
+            a = oracle.gen_codes(n, 128, 34, **kw)
+            assert np.array_equal(a, P.gen_codes(n, 128, 34, **kw))
+            assert np.array_equal(a[1000:5000], P.gen_codes(4000, 128, 34, first_id=1000, **kw))
+            q = rng.integers(0, 256, size=(5, 16), dtype=np.uint8)
+            q[0] = a[77]
+            out, cnt = P.linear_knn(a, q, 100, id_base=7)
+            for i in range(5):
+                assert np.array_equal(out[i], oracle.linear_knn(a, q[i], 100, id_base=7))
+            assert np.array_equal(oracle.linear_knn_slabbed(P, n, 128, 34, q, 100, slab=70_001, **kw),
+                                  P.linear_knn(a, q, 100)[0])
+        out, cnt = P.linear_knn(a[:30], q, 100)          # fewer records than k: padded rows, true counts
+        assert np.all(cnt == 30) and np.all(out[:, 30:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+        c64 = oracle.gen_codes(n, 64, 34)
+        q64 = c64[[5, 9]].copy()
+        q64[0, 0] ^= 3
+        for i, r in enumerate(P.linear_radius(c64, q64, 20, cap=8)):   # cap too small at first: the wrapper retries
+            d = oracle.np_distances(c64, q64[i])
+            hit = np.nonzero(d <= 20)[0]
+            assert np.array_equal(r, np.sort(oracle.pack(d[hit], hit.astype(np.uint32))))
+        rs = oracle.linear_radius_slabbed(P, n, 64, 34, q64, 20, slab=64_000)
+        assert all(np.array_equal(x, y) for x, y in zip(rs, P.linear_radius(c64, q64, 20)))

@@ -31,6 +31,68 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def kernel_resources(obj):
+    """{kernel name: {private_segment_fixed_size, sgpr_spill_count, vgpr_spill_count, vgpr_count, sgpr_count}} of the
+    gfx950 code object inside a hipcc object file: .hip_fatbin section -> offload bundle -> AMDGPU metadata note."""
+    import tempfile
+    tools = {t: os.path.join(LLVM_BIN, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")}
+    for t, path in tools.items():
+        if not os.path.exists(path):
+            raise RuntimeError("%s not found: cannot inspect the code object of %s" % (path, obj))
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "gfx950.co")
+        subprocess.check_call([tools["llvm-objcopy"], "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(td, "copy.o")])
+        subprocess.check_call([tools["clang-offload-bundler"], "--unbundle", "--type=o",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co])
+        notes = subprocess.check_output([tools["llvm-readelf"], "--notes", co]).decode(errors="replace")
+    # the note is YAML: "amdhsa.kernels:" holds one "  - .agpr_count: ..." record per kernel, keys at four spaces
+    res, rec, in_kernels = {}, None, False
+    keys = ("private_segment_fixed_size", "sgpr_spill_count", "vgpr_spill_count", "vgpr_count", "sgpr_count")
+
+    def close(r):
+        if r and "name" in r:
+            res[r.pop("name")] = r
+
+    for line in notes.splitlines():
+        if not line.startswith(" "):
+            close(rec)
+            rec, in_kernels = None, line.startswith("amdhsa.kernels:")
+            continue
+        if not in_kernels:
+            continue
+        if line.startswith("  - "):
+            close(rec)
+            rec, line = {}, "    " + line[4:]
+        if rec is None or not line.startswith("    .") :
+            continue
+        key, _, val = line[5:].partition(":")
+        if key == "name":
+            rec["name"] = val.strip().strip("'\"")
+        elif key in keys:
+            rec[key] = int(val)
+    close(rec)
+    return res
+
+
+def check_scan_code_objects(obj=None):
+    """The verify kernel issues its tile loads by hand (inline asm, vc_scan.hip): correctness depends on hipcc never
+    spilling or moving a tile register between the load and vc_tile_wait, so EVERY vc_scan_kernel instantiation must
+    have no scratch and no spills.  Raises otherwise; returns the number of instantiations checked."""
+    obj = obj or os.path.join(LIBDIR, "vc_scan.o")
+    res = kernel_resources(obj)
+    scan = {k: v for k, v in res.items() if "vc_scan_kernel" in k}
+    if not scan:
+        raise RuntimeError("no vc_scan_kernel instantiation found in %s (metadata layout changed?)" % obj)
+    bad = {k: v for k, v in scan.items()
+           if v.get("private_segment_fixed_size", 1) != 0 or v.get("vgpr_spill_count", 1) != 0 or v.get("sgpr_spill_count", 1) != 0}
+    if bad:
+        raise RuntimeError("vc_scan_kernel must not use scratch or spill next to its hand-issued loads: %s" % bad)
+    return len(scan)
+
+
 def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link the shared library."""
     if not force and not _stale():
@@ -53,6 +115,8 @@ def build(force=False, verbose=False):
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors="replace"))
             raise RuntimeError("hipcc failed on %s" % src)
+    if os.environ.get("VC_BUILD_EXTRA") is None and os.environ.get("VC_BUILD_DIAG") != "1":
+        check_scan_code_objects()      # product build only: dev experiments may spill on purpose
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
     build_host_tools()
