@@ -55,6 +55,7 @@ def parse(argv=None):
     ap.add_argument("--tables", default="2,4", help="workload c2: table counts to run (the first one is the line's value)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child run that measures roofline.traffic")
+    ap.add_argument("--no-extras", action="store_true", help="default line only: skip the short qt=32 / c2 / knn_mih measurements (`extras`)")
     args = ap.parse_args(argv)
     d = {"c3": (1e9, 128, 8, 30), "c2": (1e8, 64, 1024, 20), "c5shard": (5e8, 256, 4096, 4), "knn_mih": (1e8, 128, 4096, 10)}[args.workload]
     if args.n is None:
@@ -100,17 +101,22 @@ def cpu_baseline_linear(args, n_total):
                   % (done, sample_n, dt),
         "items_per_s": qps_sample * sample_n,
     }
-    # many host cores (BASELINE.md row CPU-linear-allcores): same scan split over threads + merge.  The port spawns its
-    # threads per query, which stops paying beyond a few dozen (256 threads were slower than 16 on the 256-core GPU box),
-    # so the row uses min(nproc, 32) threads and says so.
-    cores = min(nproc, 32)
-    t0 = time.perf_counter()
-    done = 0
-    while done < len(q) and time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
-        vo.linear_knn(codes, q[done], args.k, threads=cores)
-        done += 1
-    dt = time.perf_counter() - t0
-    res["allcores"] = {"value": done / dt * sample_n / n_total, "cores": cores, "nproc": nproc}
+    # every host core this job may use (BASELINE.md row CPU-linear-allcores): the same scan on a persistent worker pool
+    # (oracle/vc_oracle.cc VcoPool: threads created once, every worker scans its id range for the whole query batch,
+    # per-range heaps merged per query), in batches of the GPU step's size
+    with vo.Pool() as pool:
+        batch = max(1, min(args.queries, 64))
+        pool.linear_knn(codes[:200000], q[:batch], args.k)  # warm
+        t0 = time.perf_counter()
+        done = 0
+        while done + batch <= len(q) and time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
+            pool.linear_knn(codes, q[done:done + batch], args.k)
+            done += batch
+        dt = time.perf_counter() - t0
+        res["allcores"] = {"value": done / dt * sample_n / n_total, "cores": pool.threads, "nproc": nproc,
+                           "items_per_s": done / dt * sample_n,
+                           "sample": "%d queries in batches of %d x first %d codes in %.1f s on a persistent pool of %d threads; scaled by N_sample/N"
+                                     % (done, batch, sample_n, dt, pool.threads)}
     return res
 
 
@@ -243,7 +249,7 @@ def measure_traffic(args, kernel_substr, fetch_mult=2.0, extra=()):
     vals = {}
     base = ["--workload", args.workload, "--db-size", repr(float(args.n)), "--bits", str(args.bits), "--k", str(args.k),
             "--queries", str(args.queries), "--seed", str(args.seed), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
-            "--no-check", "--no-traffic"] + list(extra)
+            "--no-check", "--no-traffic", "--no-extras"] + list(extra)
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
             env = dict(os.environ, TMPDIR="/tmp")
@@ -381,6 +387,8 @@ def run_headline(args, env, emit, backend_factory=None):
     if rank == 0:
         scan_avg_ms = tm.scan_ms / max(tm.scan_launches, 1)
         bytes_per_launch = tm.scan_bytes / max(tm.scan_launches, 1)
+        resident_mb = int(os.environ.get("VC_SCAN_RESIDENT_MB", "240"))          # VC_RESIDENT_MB_DEFAULT (vc_engine.hip)
+        resident_bytes = min(resident_mb << 20, int(bytes_per_launch))
         achieved = bytes_per_launch / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
         traffic, traffic_how = None, "not measured"
         if world == 1 and env.cuda and not args.no_traffic and backend_factory is None:
@@ -414,11 +422,19 @@ def run_headline(args, env, emit, backend_factory=None):
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_how": traffic_how,
                 "kernel": "vc_scan_kernel", "launches": tm.scan_launches, "avg_launch_ms": scan_avg_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                # `achieved` is ALGORITHMIC bandwidth (every code byte once per launch).  The first resident_prefix_bytes of
+                # the database are read with cache-allocating loads and stay in the 256 MB Infinity Cache between passes
+                # (DESIGN.md 4.1): from the second pass on they do not come from HBM -- 1.5 % of a 16 GB database, 12 % of a
+                # 2 GB shard -- and FETCH_SIZE counts them all the same.  achieved_excl_resident prices only the rest.
+                "resident_prefix_bytes": resident_bytes,
+                "achieved_excl_resident": (max(bytes_per_launch - resident_bytes, 0) / (scan_avg_ms * 1e-3) / 1e9) if scan_avg_ms > 0 else 0.0,
             },
             "results_check": "ok" if ok else "FAILED",
         }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline_linear(args, n_total)
+        if world == 1 and env.cuda and backend_factory is None and not args.no_extras and n_total >= 10 ** 9:
+            line["extras"] = run_extras(args, env)
         emit(line)
     return ok
 
@@ -457,6 +473,116 @@ def _mih_roofline(tm, bits):
     }
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# extras of the default line: short measurements of the other shapes in the SAME invocation, so that the driver's
+# record carries them too (each: whole-call queries/s, the dominant kernel's average launch time and its algorithmic
+# bytes per launch; the full lines with cpu_baseline and PMC traffic are `--workload c2 / knn_mih`)
+# ---------------------------------------------------------------------------------------------------------------
+def _extra_qt32(args, env, steps=6):
+    """the same verify kernel at 32 queries per pass: the throughput optimum (VALU-bound), where 8 per pass is the HBM-bound one"""
+    torch = env.torch
+    from verticut_amd import engine as vc
+    n, Q, k = int(args.n), 32, args.k
+    rng = np.random.default_rng(args.seed + 7)
+    with vc.Engine(args.bits, capacity=n, query_tile=Q, flags=vc.FLAG_LEAN_TIMING) as e:
+        e.add_synthetic(n, seed=args.seed)
+        dq = [torch.from_numpy(rng.integers(0, 256, size=(Q, args.bits // 8), dtype=np.uint8)).to(env.device) for _ in range(2)]
+        d_out = torch.empty((Q, k), dtype=torch.int64, device=env.device)
+        d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def run_steps(count):
+            for i in range(count):
+                e.search_knn_dev(dq[i % 2].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), stream=st)
+
+        run_steps(4)
+        env.sync()
+        e.timing()
+        _, elapsed = timed_steps(env, run_steps, steps)
+        tm = e.timing()
+        res = d_out.cpu().numpy().view(np.uint64)
+        ok = bool(np.all(d_cnt.cpu().numpy() == k)) and bool(np.all(res[:, 1:] > res[:, :-1])) and e.device_status() == 0
+    launches = max(tm.scan_launches, 1)
+    return {"workload": "configs[2] at 32 queries per pass (same engine and kernel; VALU-bound)", "value": Q * steps / elapsed,
+            "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "kernel": "vc_scan_kernel", "kernel_avg_ms": tm.scan_ms / launches,
+            "algorithmic_bytes_per_launch": tm.scan_bytes / launches, "results_check": "ok" if ok else "FAILED"}
+
+
+def _extra_mih(args, env, kind, steps=6):
+    """kind 'c2': BASELINE configs[1] (64-bit, 1e8, all within 8, m = 2); 'knn_mih': exact top-100 through MIH on 1e8 clustered
+    128-bit codes -- the shapes of `--workload c2 / knn_mih`, a few steps each"""
+    torch = env.torch
+    from verticut_amd import engine as vc
+    n = 100_000_000
+    rng = np.random.default_rng(args.seed + (2 if kind == "c2" else 3))
+    if kind == "c2":
+        bits, m, Q, radius = 64, 2, 1024, 8
+        e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
+        e.add_synthetic(n, seed=args.seed)
+    else:
+        bits, m, Q, k = 128, 4, 4096, 100
+        e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
+        e.add_synthetic(n, seed=args.seed, kind=vc.SYNTH_CLUSTERED, n_centres=n // 1000, max_flips=11)
+    try:
+        e.build_index()
+        host_q = [_near_queries(e, n, Q, bits, 8 if kind == "c2" else 4, rng) for _ in range(2)]
+        dq = [torch.from_numpy(h).to(env.device) for h in host_q]
+        st = torch.cuda.current_stream().cuda_stream
+        if kind == "c2":
+            out_cap = Q * 64
+            d_out = torch.empty((out_cap,), dtype=torch.int64, device=env.device)
+            d_off = torch.empty((Q + 1,), dtype=torch.int64, device=env.device)
+
+            def run_steps(count):
+                for i in range(count):
+                    if e.search_radius_dev(dq[i % 2].data_ptr(), Q, radius, d_out.data_ptr(), out_cap, d_off.data_ptr(),
+                                           mode=vc.MODE_MIH_EXACT, stream=st) != vc.VC_OK:
+                        raise SystemExit("extras c2: results do not fit")
+        else:
+            d_out = torch.empty((Q, k), dtype=torch.int64, device=env.device)
+            d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
+
+            def run_steps(count):
+                for i in range(count):
+                    e.search_knn_dev(dq[i % 2].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), mode=vc.MODE_MIH_EXACT, stream=st)
+
+        run_steps(3)
+        env.sync()
+        e.timing()
+        _, elapsed = timed_steps(env, run_steps, steps)
+        tm = e.timing()
+        qh = host_q[(steps - 1) % 2][:16]
+        if kind == "c2":     # MIH == full scan on the last batch
+            off = d_off.cpu().numpy().view(np.uint64)
+            res = d_out.cpu().numpy().view(np.uint64)
+            lin = e.search_radius(qh, radius, mode=vc.MODE_LINEAR)
+            ok = all(np.array_equal(res[int(off[i]):int(off[i + 1])], lin[i]) for i in range(16))
+        else:                # exact MIH distances == full scan
+            lin, _ = e.search_knn(qh, k, mode=vc.MODE_LINEAR)
+            ok = bool(np.array_equal(d_out.cpu().numpy().view(np.uint64)[:16] >> np.uint64(32), lin >> np.uint64(32)))
+    finally:
+        e.close()
+    roof = _mih_roofline(tm, bits)
+    return {"workload": ("configs[1]: 64-bit, 1e8 codes, all neighbours within 8, MIH m=2, 1024 queries per call" if kind == "c2" else
+                         "exact top-100 through MIH, 128-bit, 1e8 clustered codes, m=4, 4096 queries per call"),
+            "value": Q * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3,
+            "kernel": "mih_query_kernel" if kind == "c2" else "mih_wave_kernel + mih_query_kernel",
+            "kernel_ms_per_step": tm.mih_ms / steps, "kernel_launches_per_step": tm.mih_launches / steps,
+            "algorithmic_bytes_per_step": (roof.get("algorithmic_bytes_per_launch") or 0) * tm.mih_launches / steps,
+            "per_query": roof.get("per_query"), "results_check": "ok" if ok else "FAILED"}
+
+
+def run_extras(args, env):
+    out = {}
+    for name, fn in (("qt32", lambda: _extra_qt32(args, env)), ("c2_m2", lambda: _extra_mih(args, env, "c2")),
+                     ("knn_mih_1e8", lambda: _extra_mih(args, env, "knn_mih"))):
+        try:
+            out[name] = fn()
+        except Exception as ex:   # an extra never takes the headline down with it; the failure is reported in its place
+            out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    return out
+
+
 def run_c2(args, env, emit):
     """BASELINE configs[1]: 64-bit codes, 1e8 DB, all neighbours within distance 8 through MIH (search_worker.cc:222-264)."""
     torch = env.torch
@@ -480,8 +606,10 @@ def run_c2(args, env, emit):
 
         def run_steps(count):
             for i in range(count):
-                e.search_radius_dev(dev_q[i % 2].data_ptr(), Q, radius, d_out.data_ptr(), out_cap, d_off.data_ptr(),
-                                    mode=vc.MODE_MIH_EXACT, stream=s)
+                rc = e.search_radius_dev(dev_q[i % 2].data_ptr(), Q, radius, d_out.data_ptr(), out_cap, d_off.data_ptr(),
+                                         mode=vc.MODE_MIH_EXACT, stream=s)
+                if rc != vc.VC_OK:      # VC_ERR_CAPACITY: a truncated result must never be timed as if it were complete
+                    raise SystemExit("c2: search_radius_dev returned %d (results do not fit out_cap = %d)" % (rc, out_cap))
 
         run_steps(max(args.warmup, 2))
         env.sync()

@@ -220,6 +220,54 @@ int vc_device_status(vc_engine* e, uint32_t* n_gave_up);
 int vc_merge_topk_dev(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, uint32_t k,
                       uint64_t* d_out, uint32_t* d_counts, void* stream);
 
+/* ---- one process, several GPUs --------------------------------------------------------------
+ * replaces: the reference's distribution of this path -- `mpirun -n 4` ranks (run_distributed_search.py:74), the
+ * per-radius MPI_Gather / Gatherv / Bcast between them (search_worker.cc:99-101,177,207; mpi_coordinator.cc:26-69)
+ * and the master-side dedup + heap (search_worker.cc:179-199).
+ * The database is split BY ID RANGE into n_shards shards (shard g holds ids [capacity*g/G, capacity*(g+1)/G) of the
+ * id space that starts at engine.id_base; shard g lives on device_ids[g % n_devices]); every shard answers the whole
+ * batch for its ids and the per-shard top-k rows (nq*k*8 bytes per shard -- the only inter-GPU traffic) are brought
+ * together by ONE exchange per batch and merged by the kernel behind vc_merge_topk_dev on the first device:
+ *   VC_EXCHANGE_RCCL       grouped ncclAllGather over xGMI (single-process ncclCommInitAll; one shard per device)
+ *   VC_EXCHANGE_PEER_COPY  hipMemcpyPeerAsync into the root's gather buffer (also when shards share a device)
+ *   VC_EXCHANGE_AUTO       RCCL when there is one shard per device, more than one device and librccl loads; else peer copy
+ * LINEAR results are exactly those of one engine holding everything (the top-k of a union is the top-k of the parts'
+ * top-k).  MIH modes: every shard runs to its OWN stop rule, which is exact for the shard, so exact-mode distances
+ * equal the single-engine result; statistics report the widest radius and the summed reads / candidates. */
+#define VC_MAX_SHARDS 16
+#define VC_EXCHANGE_AUTO 0
+#define VC_EXCHANGE_PEER_COPY 1
+#define VC_EXCHANGE_RCCL 2
+
+typedef struct vc_sharded vc_sharded;
+typedef struct vc_sharded_config {
+  uint32_t abi_version;            /* VC_ABI_VERSION */
+  uint32_t n_shards;               /* G: 1..VC_MAX_SHARDS (the reference's `size`, search_worker.cc:58) */
+  uint32_t n_devices;              /* entries of device_ids; 0 = devices 0..min(visible, n_shards)-1 */
+  uint32_t exchange;               /* VC_EXCHANGE_* */
+  int32_t device_ids[VC_MAX_SHARDS];
+  vc_config engine;                /* per-shard template: bits, n_tables, flags, cand_cap, query_tile ...; capacity = TOTAL
+                                      records over all shards, id_base = global id of record 0; `device` is ignored */
+} vc_sharded_config;
+
+int vc_sharded_create(const vc_sharded_config* cfg, vc_sharded** out);
+int vc_sharded_destroy(vc_sharded* h);
+const char* vc_sharded_last_error(const vc_sharded* h);     /* h may be NULL for create failures */
+int vc_sharded_exchange(const vc_sharded* h, uint32_t* kind); /* the exchange in use: VC_EXCHANGE_PEER_COPY or _RCCL */
+/* ingest in global id order (build_hash_tables.cc:40-70), routed to the shard that owns the id */
+int vc_sharded_add_codes(vc_sharded* h, const void* codes, uint64_t n);
+int vc_sharded_add_synthetic(vc_sharded* h, uint64_t n, uint64_t seed, uint32_t kind, uint32_t n_centres, uint32_t max_flips);
+int vc_sharded_size(const vc_sharded* h, uint64_t* n);
+int vc_sharded_build_index(vc_sharded* h);
+/* ID -> BinaryCode and HashIndex -> Image_List over all shards (a bucket = the shards' buckets in id order) */
+int vc_sharded_get_code(vc_sharded* h, uint32_t id, void* out);
+int vc_sharded_get_bucket(vc_sharded* h, uint32_t table, uint32_t index, uint32_t* ids, void* codes, uint32_t cap, uint32_t* n);
+/* SearchWorker::find / linear_search for a batch over all shards; arguments as vc_search_knn */
+int vc_sharded_search_knn(vc_sharded* h, const void* queries, uint32_t nq, uint32_t k, uint32_t mode, uint32_t order,
+                          uint64_t* out, uint32_t* counts, vc_query_stats* stats);
+/* borrow shard g's engine (bucket views, timing, files); its id range is [*first_id, *first_id + *n_ids) */
+int vc_sharded_shard(vc_sharded* h, uint32_t shard, vc_engine** e, uint64_t* first_id, uint64_t* n_ids);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Sums and resets the event records (synchronises with the last recorded call). */
 int vc_get_timing(const vc_engine* e, vc_timing* t);

@@ -271,3 +271,67 @@ def test_index_save_and_load(vc, oracle, tmp_path, bits, m):
         with pytest.raises(vc.VcError) as ei:
             e4.load_index(tmp_path / "junk")
         assert ei.value.code == vc.VC_ERR_INVALID
+
+
+def test_index_file_is_validated_on_load(vc, oracle, tmp_path):
+    """vc_load_index takes nothing from a file unchecked (build_hash_tables.cc's KV rows carried integrity words of their
+    own, Pilaf/integrity.h): an index saved from ANOTHER database of the same shape is refused by its code checksum, a
+    file with damaged id runs / offsets / bitmap fails the device validation pass, truncated and padded files are
+    refused by their size -- and the engine stays usable (build_index afterwards works)."""
+    n, bits, m, k = 20000, 128, 4, 10
+    codes = oracle.gen_codes(n, bits, 3, kind=1, n_centres=80, max_flips=6)
+    other = oracle.gen_codes(n, bits, 4, kind=1, n_centres=80, max_flips=6)
+    good, foreign = tmp_path / "good.vcidx", tmp_path / "foreign.vcidx"
+    for c, path in ((codes, good), (other, foreign)):
+        with vc.Engine(bits, capacity=n, n_tables=m) as e:
+            e.add_codes(c)
+            e.build_index()
+            e.save_index(path)
+    raw = bytearray(good.read_bytes())
+    header = 56                                            # magic 8 + 6 x u32 + n + checksum + file_bytes
+    assert int.from_bytes(raw[48:56], "little") == len(raw)
+    ids0 = header + 16                                     # table 0: {n_unique, offsets length}, then ids[n]
+
+    def damaged(name, mutate):
+        b = bytearray(raw)
+        mutate(b)
+        path = tmp_path / name
+        path.write_bytes(bytes(b))
+        return path
+
+    def swap_ids(b):                                       # still a permutation, but two entries sit in the wrong buckets
+        b[ids0:ids0 + 4], b[ids0 + 4 * 9000:ids0 + 4 * 9000 + 4] = b[ids0 + 4 * 9000:ids0 + 4 * 9000 + 4], b[ids0:ids0 + 4]
+
+    def big_id(b):
+        b[ids0 + 40:ids0 + 44] = (0xFFFFFFF0).to_bytes(4, "little")
+
+    def dup_id(b):
+        b[ids0 + 4:ids0 + 8] = b[ids0:ids0 + 4]
+
+    def bad_offsets(b):
+        o = ids0 + 4 * n                                   # offsets[] of table 0
+        b[o + 8:o + 12] = (n + 5).to_bytes(4, "little")
+
+    def clear_bitmap_word(b):
+        nu = int.from_bytes(raw[header:header + 8], "little")
+        bm = ids0 + 4 * n + 4 * (nu + 1)
+        i = next(i for i in range(bm, bm + (1 << 29), 4) if raw[i:i + 4] != b"\0\0\0\0")
+        b[i:i + 4] = b"\0\0\0\0"
+
+    cases = [(foreign, vc.VC_ERR_STATE), (damaged("swap", swap_ids), vc.VC_ERR_STATE), (damaged("bigid", big_id), vc.VC_ERR_STATE),
+             (damaged("dup", dup_id), vc.VC_ERR_STATE), (damaged("offs", bad_offsets), vc.VC_ERR_STATE),
+             (damaged("bitmap", clear_bitmap_word), vc.VC_ERR_STATE),
+             (damaged("trailing", lambda b: b.extend(b"xx")), vc.VC_ERR_INVALID),
+             (damaged("short", lambda b: b.__delitem__(slice(len(b) - 4096, len(b)))), vc.VC_ERR_INVALID)]
+    q = codes[[5, 77]].copy()
+    q[:, 3] ^= 0x21
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        for path, code in cases:
+            with pytest.raises(vc.VcError) as ei:
+                e.load_index(path)
+            assert ei.value.code == code, (path.name, ei.value)
+        e.load_index(good)                                 # the sound file still loads, and searches agree with a fresh build
+        a = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT)[0]
+        e.build_index()
+        assert np.array_equal(a, e.search_knn(q, k, mode=vc.MODE_MIH_EXACT)[0])

@@ -202,6 +202,57 @@ def test_device_recovery_three_position_levels(vc, oracle):
             assert e.device_status() == 0
 
 
+def test_device_recovery_gives_up_cleanly_and_works_again(vc, oracle, monkeypatch):
+    """A recovery grid that cannot meet (here: made to wait for a block that never comes, with a short spin bound) gives
+    up: the rows keep count = UINT32_MAX, the sticky counter says so once -- and the engine is NOT poisoned: barrier
+    words and step state are restored by the last block to leave, so the next call with an overflow recovers exactly
+    (regression: the give-up path used to leave the barrier words dirty for good and reported nothing)."""
+    monkeypatch.setenv("VC_RECOVER_TEST_FAIL", "2")         # the first two recover launches are sabotaged
+    monkeypatch.setenv("VC_RECOVER_SPIN_LIMIT", "200")
+    n = 400_000
+    codes = oracle.gen_codes(n, 256, 900, kind=1, n_centres=7, max_flips=0)
+    rng = np.random.default_rng(5)
+    q = codes[rng.integers(0, n, size=4)].copy()
+    q[1, 0] ^= 1
+    k = 16
+    exp, ecnt = _expect(oracle, codes, q, k)
+    with vc.Engine(256, capacity=n, query_tile=4, cand_cap=64) as e:
+        e.add_codes(codes)
+        got, cnt = _dev_search(e, q, k)                     # launch 1: gives up
+        assert np.all(cnt == np.uint32(0xFFFFFFFF))
+        assert e.device_status() == 1 and e.device_status() == 0      # counted once, then cleared
+        host, hcnt = e.search_knn(q, k)                     # launch 2 gives up as well: the host-driven fallback answers
+        assert np.array_equal(host, exp) and np.array_equal(hcnt, ecnt)
+        assert e.device_status() == 1
+        for _ in range(2):                                  # launches 3, 4: the device recovery works again
+            got, cnt = _dev_search(e, q, k)
+            assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp)
+        assert e.device_status() == 0
+        far = rng.integers(0, 256, size=(4, 32), dtype=np.uint8)      # and a step without overflow starts from clean state
+        got, cnt = _dev_search(e, far, k)
+        fexp, fcnt = _expect(oracle, codes, far, k)
+        assert np.array_equal(got, fexp) and np.array_equal(cnt, fcnt)
+
+
+@pytest.mark.parametrize("fold", ["1", "0"])
+def test_ragged_groups_hand_back_clean_state(vc, oracle, monkeypatch, fold):
+    """72 queries with tiles of 8 = one group of 64 + one of 8: the second group's bootstrap histograms sit 8 rows apart,
+    not 64, and the step's last kernel must hand exactly those back zeroed -- the NEXT call's thresholds are cut from
+    them (regression: residue of a ragged group made later thresholds too tight).  With the bootstrap cut folded into
+    the verify prologue (default) and with the separate vc_tau_init_kernel launch (VC_TAU_FOLD=0)."""
+    monkeypatch.setenv("VC_TAU_FOLD", fold)
+    n, bits, k = 300_000, 128, 40
+    rng = np.random.default_rng(72)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=500, max_flips=12)
+    with vc.Engine(bits, capacity=n, query_tile=8) as e:
+        e.add_codes(codes)
+        for nq in (72, 72, 8, 130, 5):
+            q = _queries(oracle, codes, nq, rng)
+            got, cnt = e.search_knn(q, k)
+            exp, ecnt = _expect(oracle, codes, q, k)
+            assert np.array_equal(cnt, ecnt) and np.array_equal(got, exp), nq
+
+
 def test_timing_reports_scan(vc):
     with vc.Engine(128, capacity=1 << 20) as e:
         e.add_synthetic(1 << 20, seed=1)

@@ -350,10 +350,12 @@ def test_queries_that_outlive_the_query_kernel_continue_in_the_multi_block_shell
             assert s.n_sub_reads == sum(__import__("math").comb(32, r) for r in range(s.radius + 1))
 
 
-@pytest.mark.parametrize("k", [2000, 8000])
+@pytest.mark.parametrize("k", [2000, 5000, 8000])
 def test_mih_large_k(vc, oracle, k):
-    """k = 2000 still runs in the query kernel (top-k + candidates in a 4096-entry LDS buffer); k = 8000 exceeds what one
-    block keeps in LDS and takes the multi-block path from shell 0: both equal the canonical rule and the linear scan."""
+    """k = 2000 still runs in the query kernel (top-k + candidates in a 4096-entry LDS buffer); k = 5000 needs the
+    8192-entry buffer = 82 KB of dynamic LDS, more than the classic 64 KiB per workgroup (the engine checks the device's
+    limit and falls back to the multi-block shells where it does not fit); k = 8000 exceeds what one block keeps in LDS
+    and takes the multi-block path from shell 0: all equal the canonical rule and the linear scan."""
     n, bits, m = 60000, 128, 4
     rng = np.random.default_rng(k)
     codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=6, max_flips=6)     # ~10 K items per cluster

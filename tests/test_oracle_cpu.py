@@ -186,6 +186,7 @@ def test_library_exports_every_declared_symbol(vc):
 
 def test_config_struct_layout_matches_header(vc):
     assert ctypes.sizeof(vc.VcConfig) == 64 and ctypes.sizeof(vc.VcQueryStats) == 40 and ctypes.sizeof(vc.VcTiming) == 64
+    assert ctypes.sizeof(vc.VcShardedConfig) == 16 + 16 * 4 + 64 and vc.VcShardedConfig.engine.offset == 80
 
 
 def test_product_never_imports_the_oracle():

@@ -80,19 +80,40 @@ def _worker_bucketed(rank, world, port, total_n, bits, k, ret):
 
     def check_pending():
         nonlocal ok
-        for q, (out, cnt) in pending:
+        for q, h in pending:
+            out, cnt = h.get()
             exp = np.stack([vo.linear_knn(full, q[i], k) for i in range(len(q))])
             ok = ok and np.array_equal(out.numpy().view(np.uint64), exp) and bool(np.all(cnt.numpy() == k))
         pending.clear()
 
+    from verticut_amd.sharded import PendingResult
+    ready_seen = []
     for b in range(5):
         q = full[rng.integers(0, total_n, size=4)].copy()
         q[:, b] ^= 0x21
-        pending.append((q, ss.search(torch.from_numpy(q), k)))
+        h = ss.search(torch.from_numpy(q), k)
+        ok = ok and isinstance(h, PendingResult)
+        pending.append((q, h))
+        ready_seen.append(h.ready)
         if (b + 1) % 3 == 0:
-            check_pending()          # the third call exchanged the bucket (its buffers are reused by the next bucket)
-    ss.flush()
+            ok = ok and all(x.ready for _, x in pending)       # the third call exchanged the bucket
+            check_pending()
+    ok = ok and ready_seen == [False, False, True, False, False]
+    first_of_partial = pending[0][1]
+    out, cnt = first_of_partial                                # unpacking a handle = get(): exchanges the partial bucket on demand
+    ok = ok and first_of_partial.ready and pending[1][1].ready
+    ss.flush()                                                 # nothing left to do
     check_pending()
+    # a handle that outlives two further buckets refuses to hand out recycled buffers
+    q = full[:4].copy()
+    stale = ss.search(torch.from_numpy(q), k)
+    for _ in range(2 * 3):
+        ss.search(torch.from_numpy(q), k)
+    try:
+        stale.get()
+        ok = False
+    except RuntimeError:
+        pass
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -1,0 +1,175 @@
+"""The vc_sharded_* family of the C ABI: ONE process, the database split by id range over several engines, per-shard
+top-k brought together by one exchange (peer copies, or a grouped ncclAllGather) and merged on the device -- what the
+reference does with mpirun ranks, MPI_Gather / Gatherv / Bcast per radius and a master-side heap
+(search_worker.cc:99-101,177-207; mpi_coordinator.cc:26-69).  The test box has one GPU, so several shards share it
+(peer-copy path); the RCCL path is exercised with a one-rank communicator.  Checked against the oracle over the union."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SH = np.uint64(32)
+INF = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _queries(codes, rng, nq, flips):
+    q = codes[rng.integers(0, codes.shape[0], size=nq)].copy()
+    for i in range(nq):
+        for b in rng.choice(codes.shape[1] * 8, size=int(rng.integers(0, flips + 1)), replace=False):
+            q[i, b // 8] ^= np.uint8(1 << (b % 8))
+    return q
+
+
+@pytest.mark.parametrize("bits,n,shards,id_base", [(128, 50_003, 3, 0), (64, 20_000, 4, 1000), (256, 9_999, 2, 7)])
+def test_linear_over_shards_equals_the_oracle_over_the_union(vc, oracle, bits, n, shards, id_base):
+    rng = np.random.default_rng(bits + shards)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=90, max_flips=10)
+    q = np.concatenate([_queries(codes, rng, 9, 6), rng.integers(0, 256, size=(3, bits // 8), dtype=np.uint8)])
+    k = 50
+    with vc.ShardedEngine(bits, capacity=n, n_shards=shards, devices=[0], id_base=id_base) as s:
+        assert s.exchange == vc.EXCHANGE_PEER_COPY          # several shards on one device
+        s.add_codes(codes[:777])                            # ingest in pieces that straddle shard boundaries
+        s.add_codes(codes[777:])
+        assert len(s) == n
+        ranges = [s.shard_range(g) for g in range(shards)]
+        assert ranges[0][0] == id_base and sum(c for _, c in ranges) == n
+        assert all(ranges[g][0] + ranges[g][1] == ranges[g + 1][0] for g in range(shards - 1))
+        got, cnt = s.search_knn(q, k)
+        far, _ = s.search_knn(q[:2], k, order=vc.ORDER_FARTHEST_FIRST)
+        for i in range(len(q)):
+            exp = oracle.linear_knn(codes, q[i], k, id_base=id_base)
+            assert cnt[i] == k and np.array_equal(got[i], exp)
+        assert np.array_equal(far, got[:2, ::-1])           # SearchWorker::find's order (search_worker.cc:210-216)
+        for gid in (id_base, id_base + n // 2, id_base + n - 1):
+            assert np.array_equal(s.get_code(gid), codes[gid - id_base])
+        assert s.get_code(id_base + n) is None and (id_base == 0 or s.get_code(id_base - 1) is None)
+
+
+def test_partly_filled_and_tiny_databases(vc, oracle):
+    """fewer records than capacity (the later shards stay empty), fewer records than k, fewer records than shards"""
+    bits = 128
+    codes = oracle.gen_codes(4000, bits, 5)
+    q = codes[[3, 3999]].copy()
+    q[0, 1] ^= 0x11
+    with vc.ShardedEngine(bits, capacity=12000, n_shards=3, devices=[0]) as s:
+        s.add_codes(codes)                                  # fills shard 0 exactly; shards 1 and 2 are empty
+        got, cnt = s.search_knn(q, 10)
+        for i in range(2):
+            assert np.array_equal(got[i], oracle.linear_knn(codes, q[i], 10))
+    with vc.ShardedEngine(bits, capacity=5, n_shards=3, devices=[0]) as s:
+        s.add_codes(codes[:5])
+        got, cnt = s.search_knn(q, 10)
+        for i in range(2):
+            exp = oracle.linear_knn(codes[:5], q[i], 10)
+            assert cnt[i] == 5 and np.array_equal(got[i, :5], exp) and np.all(got[i, 5:] == INF)
+
+
+def test_mih_over_shards(vc, oracle):
+    """every shard runs SearchWorker::find to its own stop rule (exact for the shard): distances equal the oracle's over
+    the union and the single engine's, ids below the k-th distance too; bucket views concatenate in id order"""
+    n, bits, m, k, shards = 60_000, 128, 4, 20, 3
+    rng = np.random.default_rng(8)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=300, max_flips=10)
+    q = _queries(codes, rng, 10, 5)
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    with vc.ShardedEngine(bits, capacity=n, n_shards=shards, n_tables=m, devices=[0]) as s, \
+            vc.Engine(bits, capacity=n, n_tables=m) as one:
+        s.add_synthetic(n, seed=34, kind=1, n_centres=300, max_flips=10)
+        s.build_index()
+        one.add_codes(codes)
+        one.build_index()
+        got, cnt, st = s.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        ref, _, rst = one.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        lin, _ = s.search_knn(q, k)
+        for i in range(len(q)):
+            ores, ost = mo.find(q[i], k, stop_mult=4)
+            o = np.sort(ores)
+            assert np.array_equal(got[i] >> SH, o >> SH) and np.array_equal(got[i] >> SH, ref[i] >> SH)
+            dk = o[-1] >> SH
+            assert set(got[i][(got[i] >> SH) < dk].tolist()) == set(o[(o >> SH) < dk].tolist())
+            assert np.array_equal(got[i] >> SH, lin[i] >> SH)
+            assert st[i].radius >= rst[i].radius and st[i].n_results == k and st[i].n_candidates >= k
+        app, acnt = s.search_knn(q, k, mode=vc.MODE_MIH_APPROX)
+        assert np.all(acnt == k) and np.all((app >> SH) >= (got >> SH))      # approximate is never better than exact
+        for t in range(m):
+            key = mo.key(codes[4321], t)
+            ids, bcodes, total = s.get_bucket(t, key)
+            exp_ids = mo.bucket(t, key)
+            assert total == len(exp_ids) and np.array_equal(ids, exp_ids) and np.array_equal(bcodes, codes[exp_ids])
+
+
+def test_duplicate_heavy_shards_recover_exactly(vc, oracle):
+    """rings that overflow inside the shards (thousands of ties at the k-th distance) are recovered on the device before
+    the exchange: the merged rows are the oracle's (linear_search.cc:44-57 keeps the lowest ids)"""
+    n = 300_000
+    codes = oracle.gen_codes(n, 256, 900, kind=1, n_centres=7, max_flips=0)
+    q = codes[[3, 1000, 77777, n - 1]].copy()
+    q[1, 0] ^= 1
+    with vc.ShardedEngine(256, capacity=n, n_shards=2, devices=[0], cand_cap=64, query_tile=4) as s:
+        s.add_codes(codes)
+        got, cnt = s.search_knn(q, 16)
+        for i in range(len(q)):
+            assert np.array_equal(got[i], oracle.linear_knn(codes, q[i], 16))
+
+
+def test_rccl_exchange_with_a_one_rank_communicator(vc, oracle):
+    """the RCCL path end to end on the one GPU there is: dlopen of librccl, ncclCommInitAll over one device, the grouped
+    ncclAllGather on the shard's stream, merge behind it"""
+    n, bits, k = 30_000, 128, 25
+    codes = oracle.gen_codes(n, bits, 11)
+    rng = np.random.default_rng(2)
+    q = _queries(codes, rng, 6, 9)
+    with vc.ShardedEngine(bits, capacity=n, n_shards=1, devices=[0], exchange=vc.EXCHANGE_RCCL) as s:
+        assert s.exchange == vc.EXCHANGE_RCCL
+        s.add_codes(codes)
+        for _ in range(2):
+            got, cnt = s.search_knn(q, k)
+            for i in range(len(q)):
+                assert np.array_equal(got[i], oracle.linear_knn(codes, q[i], k))
+    with pytest.raises(vc.VcError) as ei:                   # RCCL needs one shard per device: refused, not silently replaced
+        vc.ShardedEngine(bits, capacity=n, n_shards=2, devices=[0], exchange=vc.EXCHANGE_RCCL)
+    assert ei.value.code == vc.VC_ERR_STATE
+
+
+def test_bad_configurations_are_refused(vc):
+    for kw in ({"n_shards": 0}, {"n_shards": 17}, {"n_shards": 2, "devices": [99]}):
+        with pytest.raises(vc.VcError):
+            vc.ShardedEngine(128, capacity=100, **kw)
+    with vc.ShardedEngine(128, capacity=10, n_shards=2, devices=[0]) as s:
+        with pytest.raises(vc.VcError) as ei:
+            s.add_codes(np.zeros((11, 16), dtype=np.uint8))
+        assert ei.value.code == vc.VC_ERR_CAPACITY
+
+
+def test_driver_with_sharded_store(vc, oracle, tmp_path):
+    """distributed-image-search with VC_SHARDS=3: the reference-shaped driver over the sharded store prints the oracle's
+    distances (by-file and by-id paths)"""
+    driver = os.path.join(ROOT, "verticut_amd", "bin", "distributed-image-search")
+    n, bits, m, k = 30000, 128, 4, 10
+    rng = np.random.default_rng(5)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=150, max_flips=8)
+    q = codes[rng.integers(0, n, size=4)].copy()
+    q[:, 3] ^= 0x12
+    (tmp_path / "lsh.code").write_bytes(codes.tobytes())
+    (tmp_path / "query.code").write_bytes(q.tobytes())
+    env = dict(os.environ, VC_SHARDS="3", VC_DEVICES="0", VC_PRINT_RESULTS="1")
+    p = subprocess.run([driver, str(tmp_path / "lsh.code"), str(n), str(bits), str(bits // m), str(k), "pilaf", "0", "0", "-1",
+                        str(tmp_path / "query.code")], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr
+    blocks = re.split(r"^query \d+\n", p.stdout, flags=re.M)[1:]
+    assert len(blocks) == len(q)
+    for i, blk in enumerate(blocks):
+        pairs = [(int(a), int(b)) for a, b in re.findall(r"^(\d+) : (\d+)$", blk, flags=re.M)]
+        exp = oracle.linear_knn(codes, q[i], k)
+        assert [d for _, d in pairs] == [int(x >> SH) for x in exp[::-1]]
+        for a, d in pairs:
+            assert oracle.hamming(codes[a], q[i]) == d
+    p = subprocess.run([driver, str(tmp_path / "lsh.code"), str(n), str(bits), str(bits // m), str(k), "pilaf", "0", "0", "4321"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr
+    pairs = [(int(a), int(b)) for a, b in re.findall(r"^(\d+) : (\d+)$", p.stdout, flags=re.M)]
+    assert (4321, 0) in pairs and sorted(d for _, d in pairs) == [int(x >> SH) for x in oracle.linear_knn(codes, codes[4321], k)]

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libverticut_gpu.so")
-SOURCES = ["vc_scan.hip", "vc_mih.hip", "vc_sort.hip", "vc_engine.hip"]
+SOURCES = ["vc_scan.hip", "vc_mih.hip", "vc_sort.hip", "vc_engine.hip", "vc_sharded.hip"]
 HEADERS = ["vc_common.hpp", "vc_internal.hpp", "vc_mih.hpp", os.path.join("..", "..", "include", "verticut_gpu.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-pass-failed"]
 
@@ -117,7 +117,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s" % src)
     if os.environ.get("VC_BUILD_EXTRA") is None and os.environ.get("VC_BUILD_DIAG") != "1":
         check_scan_code_objects()      # product build only: dev experiments may spill on purpose
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     build_host_tools()
     return LIB

@@ -104,6 +104,13 @@ struct VcScanParams {
   uint32_t qs;              // stride, in words, between consecutive queries' entries of tau[] and count[] (>= 1)
   uint64_t* trace;          // diagnostic only (VC_SCAN_TRACE): [grid][2] s_memrealtime at block start / end
   uint64_t resident;        // chunks [0, resident) are read with plain (Infinity-Cache-allocating) loads, the rest non-temporal
+  // Threshold bootstrap folded into the verify prologue (small tiles): when shist is set, every block cuts the sampled
+  // distance histograms itself ([shist_copies] partial copies shist_cstride words apart, row q at shist + q * hist_stride)
+  // instead of reading tau[] -- no vc_tau_init_kernel launch, and no coherent read of the threshold lines by every block
+  const uint32_t* shist;
+  uint64_t shist_cstride;
+  uint32_t shist_copies;
+  uint32_t bits;
 };
 // The linear path gives every query its own 128-byte line for its threshold and for its ring cursor: both are read /
 // updated coherently by every wave that enters the rare path, coherent traffic to one line is served by ONE memory

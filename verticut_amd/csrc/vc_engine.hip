@@ -34,6 +34,7 @@ struct vc_engine {
   const uint32_t* clean_ptr = nullptr;  size_t clean_words = 0;
   uint32_t scan_event_tick = 0;                           // VC_FLAG_LEAN_TIMING: only every timing_sample-th verify launch is timed
   VcKnobs knobs;                                          // environment knobs, read once at vc_create
+  uint32_t recover_sabotage = 0;                          // test knob VC_RECOVER_TEST_FAIL: recover launches still to be made to give up
 
   // timing: event pairs recorded since the last vc_get_timing (calls: whole search calls, scans: verify launches)
   std::vector<hipEvent_t> ev_pool;
@@ -107,6 +108,12 @@ static void read_knobs(VcKnobs* k) {
   if (const char* v = getenv("VC_MIH_HOST_LOOP")) k->mih_host_loop = atoi(v);
   if (const char* v = getenv("VC_SCAN_SMALL")) k->scan_small = atoi(v);
   if (const char* v = getenv("VC_MIH_BUDGET")) k->mih_budget = strtoull(v, nullptr, 10);
+  if (const char* v = getenv("VC_TAU_FOLD")) k->tau_fold = atoi(v);
+  if (const char* v = getenv("VC_MIH_WAVE")) k->mih_wave = atoi(v);
+  if (const char* v = getenv("VC_MIH_WAVE_SHELLS")) k->mih_wave_shells = atoi(v);
+  if (const char* v = getenv("VC_MIH_PAIR01")) k->mih_pair01 = atoi(v);
+  if (const char* v = getenv("VC_RECOVER_SPIN_LIMIT")) k->recover_spin_limit = (uint32_t)strtoul(v, nullptr, 10);
+  if (const char* v = getenv("VC_RECOVER_TEST_FAIL")) k->recover_test_fail = (uint32_t)strtoul(v, nullptr, 10);
 }
 
 static int bind_device(vc_engine* e) {
@@ -168,6 +175,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
   e->sbits = sbits;
   e->n_cu = (uint32_t)prop.multiProcessorCount;
   read_knobs(&e->knobs);
+  e->recover_sabotage = e->knobs.recover_test_fail;
   e->cap = cfg->cand_cap ? cfg->cand_cap : 65536u;
   // queries verified per database pass: 8 keeps the pass on the HBM side of the roofline (bench), larger tiles trade
   // bandwidth efficiency for queries/s until the popcount VALU ceiling; default for big batches: 32
@@ -405,7 +413,7 @@ int vc_save_index(vc_engine* e, const char* path) {
   if (!e->mih) return fail(e, VC_ERR_STATE, "no index built");
   int rc = bind_device(e);
   if (rc) return rc;
-  return vc_mih_save(e->mih, path, e->stream, &e->err);
+  return vc_mih_save(e->mih, e->d_cols, e->stride, path, e->stream, &e->err);
 }
 
 int vc_load_index(vc_engine* e, const char* path) {
@@ -551,7 +559,7 @@ static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
 
 // one verify launch for a tile whose tau is already set (the tile's state starts at query t0 of the group); d_limit may be null
 static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint32_t qt, uint32_t k, const uint64_t* d_limit,
-                     uint32_t t0 = 0) {
+                     uint32_t t0 = 0, const uint32_t* d_shist = nullptr, uint64_t shist_cstride = 0) {
   const VcScanShape sh = vc_scan_pick_shape(e->W, qt, nullptr, &e->knobs);
   VcScanParams p{};
   p.cols = e->d_cols;
@@ -570,6 +578,10 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
   p.hist = b.d_hist + (size_t)t0 * b.hs;
   p.buf = e->d_ring + (size_t)t0 * b.cap;
   p.limit = d_limit;
+  p.shist = d_shist;             // set: the kernel's prologue cuts the bootstrap histograms itself (no vc_tau_init_kernel)
+  p.shist_cstride = shist_cstride;
+  p.shist_copies = VC_SHIST_COPIES;
+  p.bits = e->bits;
   p.wrap = e->knobs.scan_wrap;   // diagnostic build only, results are wrong by design
   p.diag = e->knobs.scan_diag;
   {   // Infinity-Cache-resident prefix (see the load in vc_scan_kernel)
@@ -661,14 +673,22 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
     // per-step state: zero from the previous step's last kernel, or (first use, new buffer, after an error) memset now
     const bool clean = e->knobs.device_recover && e->clean_ptr == e->d_state && e->clean_words >= b.state_words;
     e->clean_ptr = nullptr;
-    if (!clean) VC_HIP(e, hipMemsetAsync(e->d_state, 0, e->state_bytes, e->stream));
+    if (!clean) {
+      VC_HIP(e, hipMemsetAsync(e->d_state, 0, e->state_bytes, e->stream));
+      VC_HIP(e, hipMemsetAsync(b.d_tau, 0xFF, (size_t)b.GQ * VC_QUERY_LINE_WORDS * 4, e->stream));   // "no threshold yet"
+    }
+    // small tiles: the verify kernel's prologue turns the sampled histograms into thresholds itself (one launch less and
+    // no coherent read of the threshold lines by every block at start)
+    const bool fold = !sample2 && e->knobs.tau_fold && vc_scan_is_small(e->W, std::min(b.QT, gq), &e->knobs) &&
+                      (gq % b.QT == 0 || vc_scan_is_small(e->W, gq % b.QT, &e->knobs));
     VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample, dg, gq, b.d_shist, b.hs, k, e->bits, b.d_tau, VC_QUERY_LINE_WORDS, false,
-                                    e->n_cu, e->knobs.sample_blocks_per_cu, e->stream));
+                                    e->n_cu, e->knobs.sample_blocks_per_cu, e->stream, !fold));
     if (sample2)
       VC_HIP(e, vc_launch_sample_hist(e->d_cols, e->stride, e->W, sample2, dg, gq, b.d_shist2, b.hs, k, e->bits, b.d_tau, VC_QUERY_LINE_WORDS, true,
                                       e->n_cu, e->knobs.sample_blocks_per_cu, e->stream));
     for (uint32_t t0 = 0; t0 < gq; t0 += b.QT)
-      if ((rc = scan_tile(e, b, dg + (size_t)t0 * e->W, std::min(b.QT, gq - t0), k, nullptr, t0))) return rc;
+      if ((rc = scan_tile(e, b, dg + (size_t)t0 * e->W, std::min(b.QT, gq - t0), k, nullptr, t0,
+                          fold ? b.d_shist + (size_t)t0 * b.hs : nullptr, (uint64_t)gq * b.hs))) return rc;
     VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, VC_QUERY_LINE_WORDS, gq, k, d_out + (size_t)g0 * k,
                                     d_cnt + g0, e->stream));
     // rows whose ring overflowed (count reported as UINT32_MAX) are recomputed exactly on the device: a no-op launch otherwise
@@ -678,8 +698,11 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
                                     e->d_ring + (size_t)c0 * b.cap, b.cap, b.d_count + (size_t)c0 * VC_QUERY_LINE_WORDS,
                                     b.d_hist + (size_t)c0 * b.hs, b.hs, VC_QUERY_LINE_WORDS, e->d_rec, d_out + (size_t)(g0 + c0) * k,
                                     d_cnt + g0 + c0, b.d_tau + (size_t)c0 * VC_QUERY_LINE_WORDS, b.d_shist + (size_t)c0 * b.hs,
-                                    (uint64_t)b.GQ * b.hs, 2 * VC_SHIST_COPIES, e->n_cu, e->stream));
-    if (e->knobs.device_recover) {
+                                    (uint64_t)gq * b.hs, VC_SHIST_COPIES, e->n_cu, e->knobs.recover_spin_limit,
+                                    e->recover_sabotage ? (e->recover_sabotage--, 1u) : 0u, e->stream));
+    // the recover kernel handed the group's state back clean (the 16 partial histograms of a group of gq queries sit
+    // gq * hs words apart, which is what it was told); the refining stage's histograms (dev knob) are not covered
+    if (e->knobs.device_recover && !sample2) {
       e->clean_ptr = e->d_state;
       e->clean_words = e->state_bytes / 4;
     }
@@ -844,7 +867,13 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
     std::vector<uint32_t> over;
     for (uint32_t i = 0; i < nq; ++i)
       if (cnt[i] == 0xFFFFFFFFu) over.push_back(i);
-    if (!over.empty() && (rc = linear_recover(e, e->d_q, k, over, out, cnt.data()))) return rc;
+    if (!over.empty()) {
+      // the device recovery gave up (or is switched off): its last block restores the barrier words itself, but should
+      // that block never have run (the grid was cut short) they would stay dirty for the life of the engine -- the
+      // stream is idle here, so the three lines are simply rewritten
+      if (e->d_rec) VC_HIP(e, hipMemsetAsync(e->d_rec + vc_recover_barrier_offset_words(), 0, 96 * 4, e->stream));
+      if ((rc = linear_recover(e, e->d_q, k, over, out, cnt.data()))) return rc;
+    }
   }
   for (uint32_t i = 0; i < nq; ++i) {
     if (order == VC_ORDER_FARTHEST_FIRST) std::reverse(out + (size_t)i * k, out + (size_t)i * k + cnt[i]);

@@ -22,6 +22,12 @@ struct VcKnobs {
   int resident_mb = -1;                       // VC_SCAN_RESIDENT_MB: database prefix kept in the Infinity Cache by the verify pass (-1 = default)
   bool scan_trace = false;                    // VC_SCAN_TRACE=1 (diagnostic build): per-block start / end times of the verify kernel
   int mih_host_loop = 0;                      // VC_MIH_HOST_LOOP=1: one host round trip per shell (the round-1 loop)
+  int tau_fold = 1;                           // VC_TAU_FOLD=0: thresholds by vc_tau_init_kernel even for small tiles
+  int mih_wave = 1;                           // VC_MIH_WAVE=0: k-NN through the block-per-query kernel only (no mih_wave_kernel stage)
+  int mih_wave_shells = -1;                   // VC_MIH_WAVE_SHELLS: last shell run by mih_wave_kernel (-1 = automatic)
+  int mih_pair01 = 1;                         // VC_MIH_PAIR01=0: mih_wave_kernel scans shells 0 and 1 in separate passes
+  uint32_t recover_spin_limit = 0;            // VC_RECOVER_SPIN_LIMIT: bound of the recovery grid barrier's spin (0 = default, ~3 s)
+  uint32_t recover_test_fail = 0;             // VC_RECOVER_TEST_FAIL=N (tests): the first N recover launches wait for a block that never comes
 };
 
 // ---- vc_scan.hip ------------------------------------------------------------------------------
@@ -49,7 +55,8 @@ hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t
 hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
                                  uint32_t k, uint32_t bits, uint32_t* d_tau, uint32_t qs, bool refine, uint32_t n_cu,
-                                 uint32_t blocks_per_cu, hipStream_t s);
+                                 uint32_t blocks_per_cu, hipStream_t s, bool cut = true);
+bool vc_scan_is_small(uint32_t W, uint32_t qt, const VcKnobs* knobs);
 // grid = min(chunks, CUs x resident blocks per CU, want_blocks if non-zero)
 hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, const VcKnobs* knobs,
                           hipStream_t s);
@@ -70,7 +77,10 @@ hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, 
                              const uint64_t* d_queries, uint32_t nq, uint32_t k, uint64_t* d_ring, uint32_t cap,
                              const uint32_t* d_count, const uint32_t* d_hist, uint32_t hist_stride, uint32_t qs, uint32_t* d_scratch,
                              uint64_t* d_out, uint32_t* d_out_count, uint32_t* d_clean_tau, uint32_t* d_clean_shist,
-                             uint64_t clean_copy_stride, uint32_t clean_copies, uint32_t n_cu, hipStream_t s);
+                             uint64_t clean_copy_stride, uint32_t clean_copies, uint32_t n_cu, uint32_t spin_limit, uint32_t absent,
+                             hipStream_t s);
+// offset (words) of the three barrier lines (followed by the give-up counter line) inside the recovery scratch
+size_t vc_recover_barrier_offset_words();
 // ---- vc_sort.hip: the index builder's primitives (hand-written; no device library is linked) --------------------
 // exclusive prefix sum of L uint32 (in place allowed); d_work: vc_scan_work_words(L) words
 size_t vc_scan_work_words(uint64_t L);

@@ -154,6 +154,76 @@ __global__ void __launch_bounds__(256) mih_ranked_offsets_kernel(const uint32_t*
 }
 
 // ------------------------------------------------------------------------------------------
+// index-file validation (vc_mih_load): nothing a search kernel dereferences is taken from a file unchecked
+// ------------------------------------------------------------------------------------------
+// order-independent 64-bit digest of the resident code columns: sum over (item, word) of mix(word ^ mix(position))
+__global__ void __launch_bounds__(256) mih_checksum_kernel(const uint64_t* __restrict__ cols, uint64_t stride, uint32_t W,
+                                                           uint64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * W; e += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t j = e / n, i = e - j * n;
+    acc += vc_mix64(cols[j * stride + i] ^ vc_mix64(i * 8 + j));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, VC_WAVE);
+  if (vc_lane() == 0 && acc) atomicAdd(out, acc);
+}
+
+#define MIH_BAD_ID 1u          // ids[] entry outside [0, n)
+#define MIH_BAD_DUP 2u         // ids[] is not a permutation
+#define MIH_BAD_BUCKET 4u      // an entry does not sit in the bucket its record's key names (or that bucket is marked empty)
+#define MIH_BAD_OFFSETS 8u     // offsets[] not monotone from 0 to n
+#define MIH_BAD_RANK 16u       // blockrank[] is not the prefix sum of the bitmap's block popcounts / n_unique differs
+
+// every entry: id in range, seen once, and filed under the key of ITS record in the resident columns
+__global__ void __launch_bounds__(256) mih_validate_entries_kernel(VcTableView tv, const uint64_t* __restrict__ col, uint64_t n,
+                                                                   uint32_t shift, uint32_t mask, uint32_t sbits,
+                                                                   uint32_t* __restrict__ seen, uint32_t* __restrict__ bad) {
+  uint32_t f = 0;
+  for (uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t id = tv.ids[pos];
+    if (id >= n) { f |= MIH_BAD_ID; continue; }
+    if (atomicOr(&seen[id >> 5], 1u << (id & 31)) & (1u << (id & 31))) f |= MIH_BAD_DUP;
+    const uint32_t key = (uint32_t)(col[id] >> shift) & mask;
+    uint32_t a, b;
+    if (sbits < 32) {
+      a = tv.offsets[key];
+      b = tv.offsets[key + 1];
+    } else {
+      if (!vc_bit_test(tv.bitmap, key)) { f |= MIH_BAD_BUCKET; continue; }
+      const uint32_t rk = vc_rank32(tv.bitmap, tv.blockrank, key);
+      if (rk >= tv.n_unique) { f |= MIH_BAD_BUCKET; continue; }
+      a = tv.offsets[rk];
+      b = tv.offsets[rk + 1];
+    }
+    if (!(a <= pos && pos < b)) f |= MIH_BAD_BUCKET;
+  }
+  if (f) atomicOr(bad, f);
+}
+
+__global__ void __launch_bounds__(256) mih_validate_offsets_kernel(const uint32_t* __restrict__ offsets, uint64_t len, uint64_t n,
+                                                                   uint32_t* __restrict__ bad) {
+  uint32_t f = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t v = offsets[i];
+    if (i == 0 && v != 0) f = MIH_BAD_OFFSETS;
+    if (i + 1 == len ? (uint64_t)v != n : v > offsets[i + 1]) f = MIH_BAD_OFFSETS;
+  }
+  if (f) atomicOr(bad, f);
+}
+
+__global__ void __launch_bounds__(256) mih_validate_rank_kernel(const uint32_t* __restrict__ blockrank, const uint32_t* __restrict__ expect,
+                                                                const uint32_t* __restrict__ blockpop, uint32_t nblocks,
+                                                                uint32_t n_unique, uint32_t* __restrict__ bad) {
+  uint32_t f = 0;
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += gridDim.x * blockDim.x) {
+    if (blockrank[b] != expect[b]) f = MIH_BAD_RANK;
+    if (b + 1 == nblocks && expect[b] + blockpop[b] != n_unique) f = MIH_BAD_RANK;
+  }
+  if (f) atomicOr(bad, f);
+}
+
+// ------------------------------------------------------------------------------------------
 // search state
 // ------------------------------------------------------------------------------------------
 struct MihState {          // all arrays indexed by the query's slot in the tile
@@ -557,6 +627,14 @@ struct QueryKernelParams {
   uint32_t* heavy_ctr;
   uint64_t* out;               // k-NN: [nq][k] rows
   uint32_t* out_cnt;
+  // continuation of queries another kernel (mih_wave_kernel) left unfinished: block b serves slot_list[b] and resumes
+  // at shell r_first from the state that kernel handed over (st.topk / count / seen / sub / loc); null = fresh queries
+  const uint32_t* slot_list;
+  const uint32_t* slot_count;  // with slot_list: device counter of listed slots -- blocks beyond it leave at once, so the
+                               // continuation can be launched with an upper-bound grid and no host round trip in between
+  uint32_t r_first;
+  uint32_t nq;                 // mih_wave_kernel: queries of the launch (one wave each)
+  uint32_t pair01;             // mih_wave_kernel: scan shells 0 and 1 in one pass
 };
 
 __device__ __forceinline__ uint32_t mq_unrank(const uint32_t* sb, uint32_t j, uint32_t r, uint32_t s) {
@@ -588,7 +666,8 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   __shared__ uint32_t s_segstart[28], s_segh[27], s_segmask[27], s_nseg;
   __shared__ uint64_t s_thresh;
 
-  const uint32_t slot = blockIdx.x;
+  if (p.slot_count && blockIdx.x >= *p.slot_count) return;
+  const uint32_t slot = p.slot_list ? p.slot_list[blockIdx.x] : blockIdx.x;
   const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
   const uint32_t s = p.sbits, m = p.m;
   const uint32_t smask = s == 32 ? 0xFFFFFFFFu : ((1u << s) - 1u);
@@ -744,9 +823,13 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 
     uint32_t seen_acc = 0;
     for (uint32_t e0 = 0; e0 < total; e0 += MQ_ROUND) {
-      // room for one round of survivors behind what the buffer already holds (the barrier makes the fill uniform)
+      // room for one round of survivors behind what the buffer already holds.  The fill is read between two barriers:
+      // the first ends the previous round's appends, the second keeps a fast wave's appends of THIS round from being
+      // seen by a wave that has not read yet (a lone wave taking the merge branch would deadlock the block).
       __syncthreads();
-      if (kk + s_ncand + MQ_ROUND > p.buf_entries) {
+      const uint32_t fill = s_ncand;
+      __syncthreads();
+      if (kk + fill + MQ_ROUND > p.buf_entries) {
         if (knn) merge(); else flush_ring();
       }
       const uint64_t thresh = s_thresh;
@@ -1020,6 +1103,17 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   };
 
   const uint32_t S = s;            // loop bound radius <= n_local_bytes_ * 8 (search_worker.cc:170)
+  if (knn && p.r_first) {          // resume: the state mih_wave_kernel handed over after shell r_first - 1
+    kk = min(p.st.count[slot], p.k);
+    for (uint32_t i = tid; i < kk; i += MQ_BLK) s_buf[i] = p.st.topk[(uint64_t)slot * p.k + i];
+    sub = p.st.sub[slot];
+    loc = p.st.loc[slot];
+    if (tid == 0) {
+      s_seen = (uint32_t)p.st.seen[slot];
+      s_thresh = p.st.thresh[slot];
+    }
+    __syncthreads();
+  }
   if (!knn) {
     // fixed-radius neighbour search, every item within the full distance R kept.  Pigeonhole with the sharper radii of
     // multi-index hashing: R = m q + a  =>  tables 0..a search substring radius q, tables a+1..m-1 only q - 1 (were every
@@ -1066,7 +1160,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     return;
   }
 
-  for (uint32_t r = 0; r <= p.r_last; ++r) {
+  for (uint32_t r = p.r_first; r <= p.r_last; ++r) {
     if (s == 32) {
       plan32(r, false);
       scan32();
@@ -1125,14 +1219,534 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 }
 
 
+// =============================================================================================================
+// mih_wave_kernel -- ONE WAVE runs a query's radius loop (32-bit substrings, k-NN modes, shells 0..r_last).
+//
+// The block-per-query kernel above spends a near-duplicate query's life waiting: 256 threads for the 108 granules of
+// shells 0 + 1, a workgroup barrier around every phase, a 55-stage bitonic network after every shell, four queries
+// resident per CU.  A query's work is a latency chain (granule -> block directory -> record), so the way to more
+// queries per second is more queries in flight: here a query owns 64 lanes and ~8 KB of LDS, 16 queries are resident
+// per CU, and nothing in the loop needs a workgroup barrier (a wave runs in lock step; LDS operations of one wave
+// complete in order).  Differences to the block kernel, none of them visible in results or statistics:
+//   * shells 0 and 1 are scanned in ONE pass (their 1 + 26 granules per table): candidates of shell 1 carry a tag bit
+//     and their own histogram / seen counter, the stop rule is first evaluated on shell 0's candidates alone
+//     (search_worker.cc:201-205), then the tags are cleared and it is evaluated for shell 1 -- one memory round trip
+//     less for every query that needs a second shell;
+//   * no sort per shell: the k-th distance of the stop rule and the append threshold come from a distance histogram in
+//     LDS (cut = smallest d whose cumulative count reaches k); entries beyond the threshold are compacted away only
+//     when the buffer fills, and the buffer is sorted once, when the query ends (or when ties overfill it).
+// Queries that are not finished after shell r_last hand their state over exactly as the block kernel does; the host
+// continues them in the block kernel (p.slot_list / p.r_first) and then in the multi-block shells.
+// =============================================================================================================
+#define MW_HM 256u                      // hit list entries per wave
+#define MW_HFLUSH 192u
+#ifndef MW_G
+#define MW_G 4u                         // granules per lane per pass
+#endif
+#ifndef MW_EPT
+#define MW_EPT 4u                       // bucket entries per lane per round
+#endif
+#ifndef MW_WAVES
+#define MW_WAVES 3                      // waves per SIMD the kernel is compiled for (3: <= 168 VGPRs, no spills at W <= 2)
+#endif
+#define MW_ROUND (VC_WAVE * MW_EPT)
+#define MW_TAG (1ull << 63)             // candidate of the second shell of a paired pass
+#define MW_MAXSEG 20u
+
+__device__ __forceinline__ void mw_sync() {   // orders one wave's LDS traffic for the compiler (the hardware keeps it in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// smallest d with sum_{d' <= d} h[d'] >= k, 0xFFFFFFFF if the histogram holds fewer than k (one wave, LDS histogram)
+__device__ __forceinline__ uint32_t mw_hist_cut(const uint32_t* h, uint32_t nbins, uint32_t k) {
+  const uint32_t lane = vc_lane();
+  const uint32_t bpl = (nbins + VC_WAVE - 1) / VC_WAVE;
+  uint32_t mine = 0;
+  for (uint32_t i = 0; i < bpl; ++i) {
+    const uint32_t bin = lane * bpl + i;
+    if (bin < nbins) mine += h[bin];
+  }
+  uint32_t total;
+  uint32_t run = vc_wave_excl_scan(mine, total);
+  uint32_t cand = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < bpl; ++i) {
+    const uint32_t bin = lane * bpl + i;
+    if (bin < nbins) {
+      run += h[bin];
+      if (run >= k && cand == 0xFFFFFFFFu) cand = bin;
+    }
+  }
+  return vc_wave_min(cand);
+}
+
+static __host__ __device__ inline uint32_t mw_hist_bins(uint32_t W) { return (W * 64u + 1u + 7u) & ~7u; }
+// per-wave LDS of mih_wave_kernel: candidate buffer | hit list (key, prefix, meta) | 2 distance histograms | masks | segment plan
+static __host__ __device__ inline size_t mw_wave_bytes(uint32_t cb, uint32_t W, uint32_t m) {
+  const size_t b = (size_t)cb * 8 + (size_t)(3 * MW_HM + 1) * 4 + (size_t)2 * mw_hist_bins(W) * 4 +
+                   (size_t)m * (MQ_LO_KNN + 1) * ((1u << MQ_LO_KNN) / 32u) * 4 + (size_t)(4 * MW_MAXSEG + 4) * 4;
+  return (b + 15) & ~(size_t)15;
+}
+static __host__ __device__ inline size_t mw_shared_bytes(uint32_t m) {
+  return (((size_t)m * sizeof(VcTableView) + (size_t)33 * MQ_BW * 4) + 15) & ~(size_t)15;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256, MW_WAVES) mih_wave_kernel(const QueryKernelParams p) {
+  constexpr uint32_t LO = MQ_LO_KNN, HI = 32u - LO, GW = (1u << LO) / 32u, NJ = LO + 1u;
+  static_assert(GW == 4, "one 16-byte load per granule");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
+  const uint32_t m = p.m, CB = p.buf_entries, HB = mw_hist_bins(W);
+  VcTableView* s_tv = (VcTableView*)smem;
+  uint32_t* s_binom = (uint32_t*)(s_tv + m);
+  unsigned char* wb = smem + mw_shared_bytes(m) + (size_t)wave * mw_wave_bytes(CB, W, m);
+  uint64_t* cbuf = (uint64_t*)wb;                    // [CB] candidates (unsorted until the end)
+  uint32_t* hkey = (uint32_t*)(cbuf + CB);           // [MW_HM] bucket key, then entry offset
+  uint32_t* hpref = hkey + MW_HM;                    // [MW_HM + 1] bucket length, then exclusive prefix
+  uint32_t* hmeta = hpref + MW_HM + 1;               // [MW_HM] table | substring distance << 8
+  uint32_t* hist = hmeta + MW_HM;                    // [2][HB]: shells evaluated so far + the pass's first shell | its second shell
+  uint32_t* mask = hist + 2 * HB;                    // [m][NJ][GW]
+  uint32_t* segstart = mask + m * NJ * GW;           // [MW_MAXSEG + 1]
+  uint32_t* segh = segstart + MW_MAXSEG + 1;         // [MW_MAXSEG] |hi| of the segment
+  uint32_t* segj = segh + MW_MAXSEG;                 // [MW_MAXSEG] flips inside the low part (mask index)
+  uint32_t* segr = segj + MW_MAXSEG;                 // [MW_MAXSEG] shell of the segment
+
+  for (uint32_t i = threadIdx.x; i < 33 * MQ_BW; i += blockDim.x) s_binom[i] = c_binom[i / MQ_BW][i % MQ_BW];
+  for (uint32_t i = threadIdx.x; i < m * (sizeof(VcTableView) / 4); i += blockDim.x) ((uint32_t*)s_tv)[i] = ((const uint32_t*)p.tables)[i];
+  __syncthreads();                                   // the only workgroup barrier: the tables above are shared by the four waves
+  const uint32_t slot = blockIdx.x * (blockDim.x / VC_WAVE) + wave;
+  if (slot >= p.nq) return;
+
+  uint64_t qw[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) qw[j] = p.queries[(uint64_t)slot * W + j];
+  auto qkey = [&](uint32_t t) {
+    const uint32_t bp = t * 32u;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if ((uint32_t)j == (bp >> 6)) v = (uint32_t)(qw[j] >> (bp & 63));
+    return v;
+  };
+
+  for (uint32_t i = lane; i < 2 * HB; i += VC_WAVE) hist[i] = 0;
+  for (uint32_t i = lane; i < m * NJ * GW; i += VC_WAVE) mask[i] = 0;
+  mw_sync();
+  for (uint32_t i = lane; i < (m << LO); i += VC_WAVE) {   // E_j[t] = { x < 2^LO : popcount(x ^ qlo_t) = j }
+    const uint32_t t = i >> LO, x = i & ((1u << LO) - 1u);
+    const uint32_t j = __popc(x ^ (qkey(t) & ((1u << LO) - 1u)));
+    atomicOr(&mask[(t * NJ + j) * GW + (x >> 5)], 1u << (x & 31));
+  }
+  mw_sync();
+
+  // wave-uniform state
+  uint32_t fill = 0;                       // entries in cbuf
+  uint64_t thr = VC_PACK_INF;              // append iff packed < thr (exclusive bound on what can still be in the top-k)
+  uint32_t seenA = 0, seenB = 0;           // distinct items verified: shells evaluated so far + the pass's first shell | its second shell
+  uint32_t hits0A = 0, hits0B = 0;         // table 0's leaves whose bitmap bit is set (VC_FLAG_USE_BITMAP statistics)
+  uint32_t nh = 0;                         // hit list fill (may exceed MW_HM until drained)
+  uint32_t r_tag = 0xFFFFFFFFu;            // substring distance that marks the second shell of a paired pass
+  unsigned long long sub = 0, loc = 0, w_probes = 0, w_hits = 0, w_entries = 0;
+
+  auto wave_sort = [&](uint32_t P) {       // bitonic network over cbuf[0..P), one wave
+    for (uint32_t size = 2; size <= P; size <<= 1)
+      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+        mw_sync();
+        for (uint32_t i = lane; i < (P >> 1); i += VC_WAVE) {
+          const uint32_t lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+          const uint64_t x = cbuf[lo], y = cbuf[hi];
+          if ((x > y) == ((lo & size) == 0)) {
+            cbuf[lo] = y;
+            cbuf[hi] = x;
+          }
+        }
+      }
+    mw_sync();
+  };
+  // drop what the threshold has overtaken (and, when asked, the tagged entries); order is not preserved across calls
+  auto compact = [&](bool drop_tagged) {
+    uint32_t nf = 0;
+    for (uint32_t base = 0; base < fill; base += VC_WAVE) {
+      const uint32_t i = base + lane;
+      const uint64_t v = i < fill ? cbuf[i] : VC_PACK_INF;
+      const bool keep = i < fill && (v & ~MW_TAG) < thr && !(drop_tagged && (v & MW_TAG));
+      const uint64_t km = __ballot(keep);
+      mw_sync();                            // every lane has read its entry before any lane overwrites one
+      if (keep) cbuf[nf + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = v;
+      nf += (uint32_t)__popcll(km);
+    }
+    mw_sync();
+    fill = nf;
+  };
+  // exact selection when ties overfill the buffer: sort (tagged entries behind the untagged ones), keep the k best of
+  // either kind -- a superset of the top-k of the first shell alone and of both shells together
+  auto select_exact = [&]() {
+    uint32_t P = 2;
+    while (P < fill) P <<= 1;
+    for (uint32_t i = fill + lane; i < P; i += VC_WAVE) cbuf[i] = VC_PACK_INF;
+    wave_sort(P);
+    uint32_t nU = 0;                        // untagged entries (they sort first)
+    for (uint32_t base = 0; base < fill; base += VC_WAVE) {
+      const uint32_t i = base + lane;
+      nU += (uint32_t)__popcll(__ballot(i < fill && !(cbuf[i] & MW_TAG)));
+    }
+    const uint32_t keepU = min(nU, p.k), keepT = min(fill - nU, p.k);
+    for (uint32_t base = 0; base < keepT; base += VC_WAVE) {   // tagged survivors move up behind the untagged ones
+      const uint32_t i = base + lane;
+      const uint64_t v = i < keepT ? cbuf[nU + i] : 0;
+      mw_sync();
+      if (i < keepT) cbuf[keepU + i] = v;
+    }
+    mw_sync();
+    fill = keepU + keepT;
+    if (nU >= p.k) {                        // k-th best of the first shell(s): an exact bound for everything still to come
+      const uint64_t kv = cbuf[p.k - 1] + 1;
+      const uint64_t kth = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(kv >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)kv);
+      if (kth < thr) thr = kth;
+    }
+  };
+
+  // ---- drain the hit list: entry offsets, prefix sum of the bucket lengths, balanced verify (see mih_query_kernel)
+  auto drain = [&]() {
+    mw_sync();
+    const uint32_t H = min(nh, MW_HM);
+    for (uint32_t i = lane; i < H; i += VC_WAVE) {
+      const uint32_t key = hkey[i];
+      const VcTableView& tv = s_tv[hmeta[i] & 0xFFu];
+      const uint32_t blk = key >> 8, wq = (key >> 5) & 7u;
+      const uint4* bw = reinterpret_cast<const uint4*>(tv.bitmap + ((uint64_t)blk << 3));
+      const uint4 b0 = bw[0], b1 = bw[1];
+      const uint32_t o0 = tv.blockoff[blk], o1 = tv.blockoff[blk + 1];
+      const uint32_t wv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      uint32_t below = 0, all = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        all += __popc(wv[j]);
+        below += j < wq ? __popc(wv[j]) : (j == wq ? __popc(wv[j] & ((1u << (key & 31)) - 1u)) : 0u);
+      }
+      uint32_t a, len;
+      if (o1 - o0 == all) {                 // every bucket of the block holds one entry
+        a = o0 + below;
+        len = 1;
+      } else {
+        const uint32_t rk = tv.blockrank[blk] + below;
+        a = tv.offsets[rk];
+        len = tv.offsets[rk + 1] - a;
+      }
+      hkey[i] = a;
+      hpref[i] = len;
+    }
+    mw_sync();
+    uint32_t lsum = 0, lv[MW_HM / VC_WAVE];
+#pragma unroll
+    for (uint32_t i = 0; i < MW_HM / VC_WAVE; ++i) {
+      const uint32_t idx = lane * (MW_HM / VC_WAVE) + i;
+      lv[i] = idx < H ? hpref[idx] : 0;
+      lsum += lv[i];
+    }
+    uint32_t total_v;
+    uint32_t excl = vc_wave_excl_scan(lsum, total_v);
+    const uint32_t total = __builtin_amdgcn_readfirstlane(total_v);
+    mw_sync();
+#pragma unroll
+    for (uint32_t i = 0; i < MW_HM / VC_WAVE; ++i) {
+      const uint32_t idx = lane * (MW_HM / VC_WAVE) + i;
+      if (idx < H) hpref[idx] = excl;
+      excl += lv[i];
+    }
+    if (lane == 0) hpref[H] = total;
+    mw_sync();
+    w_hits += H;
+    w_entries += total;
+
+    for (uint32_t e0 = 0; e0 < total; e0 += MW_ROUND) {
+      if (fill + MW_ROUND > CB) {           // room for one round of survivors
+        compact(false);
+        if (fill + MW_ROUND > CB) select_exact();
+      }
+      uint32_t local[MW_EPT], meta[MW_EPT];
+      uint64_t x[MW_EPT][W];
+      bool live[MW_EPT];
+#pragma unroll
+      for (uint32_t g = 0; g < MW_EPT; ++g) {
+        const uint32_t e = e0 + g * VC_WAVE + lane;
+        live[g] = e < total;
+        const uint32_t ec = live[g] ? e : 0;
+        uint32_t lo = 0, hi = H;            // largest b with hpref[b] <= e
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (hpref[mid] <= ec) lo = mid; else hi = mid;
+        }
+        meta[g] = hmeta[lo];
+        const VcTableView& tv = s_tv[meta[g] & 0xFFu];
+        const uint32_t pos = hkey[lo] + (ec - hpref[lo]);
+        if (W <= 2 && tv.bent) {
+          const uint4 rec = tv.bent[(uint64_t)pos * W];
+          local[g] = rec.x;
+          x[g][0] = ((uint64_t)rec.w << 32) | rec.z;
+          if (W == 2) {
+            const uint4 rec1 = tv.bent[(uint64_t)pos * 2 + 1];
+            x[g][W - 1] = ((uint64_t)rec1.y << 32) | rec1.x;
+          }
+          continue;
+        }
+        local[g] = tv.ids[pos];
+#pragma unroll
+        for (int j = 0; j < W; ++j) x[g][j] = p.cols[(uint64_t)j * p.stride + local[g]];
+      }
+#pragma unroll
+      for (uint32_t g = 0; g < MW_EPT; ++g) {
+        bool emit = live[g];
+        uint64_t packed = 0;
+        uint32_t dist = 0;
+        const uint32_t t = meta[g] & 0xFFu, dt = meta[g] >> 8;
+        if (live[g]) {
+          for (uint32_t tt = 0; tt < m; ++tt) {
+            const uint32_t bp = tt * 32u;
+            uint32_t field = 0;
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+              if ((uint32_t)j == (bp >> 6)) field = (uint32_t)((x[g][j] ^ qw[j]) >> (bp & 63));
+            const uint32_t d = __popc(field);
+            dist += d;
+            // owner rule (mih_probe_kernel): reported by the first table holding the minimum substring distance
+            if (tt != t && (d < dt || (d == dt && tt < t))) emit = false;
+          }
+          packed = vc_pack(dist, p.id_base + local[g]);
+        }
+        const uint64_t emask = __ballot(emit);
+        if (emask == 0) continue;
+        const bool second = dt == r_tag;    // per lane: the entries of one round come from different buckets
+        const uint64_t bmask = __ballot(emit && second);
+        seenB += (uint32_t)__popcll(bmask);
+        seenA += (uint32_t)__popcll(emask & ~bmask);
+        const bool keep = emit && packed < thr;
+        const uint64_t kmask = __ballot(keep);
+        if (kmask == 0) continue;
+        if (keep) {
+          cbuf[fill + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull))] = second ? (packed | MW_TAG) : packed;
+          atomicAdd(&hist[(second ? HB : 0u) + dist], 1u);
+        }
+        fill += (uint32_t)__popcll(kmask);
+      }
+    }
+    mw_sync();
+    nh = 0;
+  };
+
+  // ---- granule scan over the segments of the pass (one or two shells of ALL tables; item = table * per_table + pattern)
+  auto scan = [&]() {
+    const uint32_t nseg = __builtin_amdgcn_readfirstlane(segstart[MW_MAXSEG]);
+    const uint32_t per_table = __builtin_amdgcn_readfirstlane(segstart[nseg]);
+    const uint32_t total = per_table * m;
+    for (uint32_t base = 0; base < total; base += VC_WAVE * MW_G) {
+      const uint32_t idx0 = base + lane * MW_G;
+      uint32_t t = 0, rem = 0, seg = 0, hi = 0;
+      if (idx0 < total) {
+        t = idx0 / per_table;
+        rem = idx0 - t * per_table;
+        while (rem >= segstart[seg + 1]) ++seg;
+        hi = mq_unrank(s_binom, rem - segstart[seg], segh[seg], HI);
+      }
+      uint4 v[MW_G];
+      uint32_t gr[MW_G], meta0[MW_G], mi[MW_G], qlo[MW_G];   // meta0 = table | |hi| << 8 | (second shell of the pass) << 31
+#pragma unroll
+      for (uint32_t g = 0; g < MW_G; ++g) {
+        const uint32_t idx = idx0 + g;
+        gr[g] = 0; meta0[g] = 0; mi[g] = 0; qlo[g] = 0;
+        v[g] = make_uint4(0, 0, 0, 0);
+        if (idx < total) {
+          if (g) {
+            ++rem;
+            if (rem == per_table) {
+              ++t;
+              rem = 0;
+              seg = 0;
+              hi = (1u << segh[0]) - 1u;
+            } else if (rem == segstart[seg + 1]) {
+              ++seg;
+              hi = (1u << segh[seg]) - 1u;
+            } else {
+              hi = vc_next_comb(hi);
+            }
+          }
+          const uint32_t qk = qkey(t);
+          gr[g] = (qk >> LO) ^ hi;
+          qlo[g] = qk & ((1u << LO) - 1u);
+          meta0[g] = t | (segh[seg] << 8) | (segr[seg] == r_tag ? 0x80000000u : 0u);
+          mi[g] = t * NJ + segj[seg];
+          v[g] = *reinterpret_cast<const uint4*>(s_tv[t].bitmap + (uint64_t)gr[g] * GW);
+        }
+      }
+      uint32_t w[MW_G][GW];
+      uint32_t cnt = 0, c0a = 0, c0b = 0;
+#pragma unroll
+      for (uint32_t g = 0; g < MW_G; ++g) {
+        const uint32_t* mk = mask + mi[g] * GW;
+        w[g][0] = v[g].x & mk[0];
+        w[g][1] = v[g].y & mk[1];
+        w[g][2] = v[g].z & mk[2];
+        w[g][3] = v[g].w & mk[3];
+        const uint32_t c = __popc(w[g][0]) + __popc(w[g][1]) + __popc(w[g][2]) + __popc(w[g][3]);
+        cnt += c;
+        if ((meta0[g] & 0xFFu) == 0 && idx0 + g < per_table) {   // table 0's leaves (get_stat of rank 0)
+          if (meta0[g] >> 31) c0b += c; else c0a += c;
+        }
+      }
+      if (p.flags & VC_FLAG_USE_BITMAP) {
+        uint32_t ta, tb;
+        (void)vc_wave_excl_scan(c0a, ta);
+        (void)vc_wave_excl_scan(c0b, tb);
+        hits0A += __builtin_amdgcn_readfirstlane(ta);
+        hits0B += __builtin_amdgcn_readfirstlane(tb);
+      }
+      for (;;) {   // append this pass's hits; what does not fit waits for a drain
+        if (__ballot(cnt != 0) == 0) break;
+        uint32_t wtot_v;
+        uint32_t pos = nh + vc_wave_excl_scan(cnt, wtot_v);
+        const uint32_t wtot = __builtin_amdgcn_readfirstlane(wtot_v);
+#pragma unroll
+        for (uint32_t g = 0; g < MW_G; ++g)
+#pragma unroll
+          for (uint32_t i = 0; i < GW; ++i)
+            while (w[g][i] && pos < MW_HM) {
+              const uint32_t bb = (uint32_t)__ffs((int)w[g][i]) - 1u;
+              w[g][i] &= w[g][i] - 1u;
+              const uint32_t xx = i * 32 + bb;
+              hkey[pos] = (gr[g] << LO) | xx;
+              hmeta[pos] = (meta0[g] & 0xFFFFu) + (__popc(xx ^ qlo[g]) << 8);
+              ++pos;
+              --cnt;
+            }
+        nh += wtot;
+        const uint32_t nh_now = nh;
+        if (nh_now >= MW_HFLUSH) drain();
+        if (nh_now <= MW_HM) break;          // everything fitted
+      }
+    }
+  };
+
+  // segments of a pass over shells r_lo..r_hi: (shell r, |hi| = h, low flips j = r - h <= LO)
+  auto plan = [&](uint32_t r_lo, uint32_t r_hi) {
+    mw_sync();
+    if (lane == 0) {
+      uint32_t ns = 0, start = 0;
+      for (uint32_t r = r_lo; r <= r_hi; ++r)
+        for (uint32_t h = 0; h <= min(r, HI); ++h) {
+          const uint32_t j = r - h;
+          if (j > LO) continue;
+          segstart[ns] = start;
+          segh[ns] = h;
+          segj[ns] = j;
+          segr[ns] = r;
+          start += s_binom[HI * MQ_BW + h];
+          ++ns;
+        }
+      segstart[ns] = start;
+      segstart[MW_MAXSEG] = ns;
+    }
+    mw_sync();
+  };
+
+  auto put_state = [&](uint32_t r) {
+    if (lane == 0) {
+      p.st.work[slot * 4 + 0] = w_probes;
+      p.st.work[slot * 4 + 1] = w_hits;
+      p.st.work[slot * 4 + 2] = w_entries;
+      p.st.radius[slot] = r;
+      p.st.seen[slot] = seenA;
+      p.st.sub[slot] = sub;
+      p.st.loc[slot] = loc;
+    }
+  };
+  // sorted top-k of what the evaluated shells have seen: cbuf[0 .. kk)
+  auto finish_sort = [&]() -> uint32_t {
+    compact(true);
+    uint32_t P = 2;
+    while (P < fill) P <<= 1;
+    for (uint32_t i = fill + lane; i < P; i += VC_WAVE) cbuf[i] = VC_PACK_INF;
+    wave_sort(P);
+    return min(fill, p.k);
+  };
+
+  const uint32_t S = 32;                   // loop bound radius <= n_local_bytes_ * 8 (search_worker.cc:170)
+  for (uint32_t r = 0; r <= p.r_last;) {
+    const uint32_t r_hi = (r == 0 && p.pair01 && p.r_last >= 1) ? 1u : r;
+    r_tag = r_hi != r ? r_hi : 0xFFFFFFFFu;
+    plan(r, r_hi);
+    scan();
+    if (nh) drain();
+    for (uint32_t rr = r; rr <= r_hi; ++rr) {
+      if (rr != r) {                       // second shell of the pass: its candidates join the evaluated set
+        for (uint32_t i = lane; i < HB; i += VC_WAVE) {
+          hist[i] += hist[HB + i];
+          hist[HB + i] = 0;
+        }
+        for (uint32_t i = lane; i < fill; i += VC_WAVE) cbuf[i] &= ~MW_TAG;
+        mw_sync();
+        seenA += seenB;
+        seenB = 0;
+        hits0A = hits0B;
+        hits0B = 0;
+        r_tag = 0xFFFFFFFFu;
+      }
+      const unsigned long long leaves = c_binom[S][rr];
+      w_probes += leaves * m;
+      if (p.flags & VC_FLAG_USE_BITMAP) {
+        loc += leaves;
+        sub += hits0A;
+      } else {
+        sub += leaves;
+      }
+      hits0A = 0;
+      mw_sync();
+      const uint32_t dk = seenA >= p.k ? __builtin_amdgcn_readfirstlane(mw_hist_cut(hist, W * 64u + 1u, p.k)) : 0xFFFFFFFFu;
+      bool stop;
+      if (p.mode == MQ_MODE_APPROX)        // search_worker.cc:136-137: the heap of k*20 distinct candidates is full
+        stop = seenA >= p.k * MIH_APPROX_FACTOR;
+      else                                 // search_worker.cc:201-205: size == k && top.dist <= radius * 4 (radius already incremented)
+        stop = dk != 0xFFFFFFFFu && dk <= (rr + 1) * p.stop_mult;
+      if (stop || rr == S) {
+        const uint32_t kk = finish_sort();
+        for (uint32_t i = lane; i < p.k; i += VC_WAVE) p.out[(uint64_t)slot * p.k + i] = i < kk ? cbuf[i] : VC_PACK_INF;
+        if (lane == 0) p.out_cnt[slot] = kk;
+        put_state(rr);
+        return;
+      }
+      if (dk != 0xFFFFFFFFu) {             // everything farther than the k-th distance is out for good
+        const uint64_t b = ((uint64_t)dk + 1) << 32;
+        if (b < thr) thr = b;
+      }
+    }
+    r = r_hi + 1;
+  }
+  // not finished: hand the query over (state exactly as mih_commit_kernel / mih_query_kernel leave it)
+  const uint32_t kk = finish_sort();
+  for (uint32_t i = lane; i < kk; i += VC_WAVE) p.st.topk[(uint64_t)slot * p.k + i] = cbuf[i];
+  put_state(0);
+  if (lane == 0) {
+    p.st.count[slot] = kk;
+    p.st.prev[slot] = kk;
+    p.st.thresh[slot] = kk == p.k ? cbuf[p.k - 1] : VC_PACK_INF;
+    p.st.topn[slot] = kk;
+    p.heavy_list[atomicAdd(p.heavy_ctr, 1u)] = slot;
+  }
+}
+
+
 // sum the per-query work counters of one mih_query_kernel launch into the index-wide totals (vc_get_timing)
 __global__ void __launch_bounds__(256) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
-                                                              unsigned long long* __restrict__ totals) {
+                                                              unsigned long long* __restrict__ totals, const uint32_t* __restrict__ list,
+                                                              uint32_t count_queries, const uint32_t* __restrict__ list_count) {
+  if (list_count) nq = min(nq, *list_count);
   __shared__ unsigned long long s_t[3];
   if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long a = 0, b = 0, c = 0;
-  for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
+  for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) {
+    const uint32_t i = list ? list[j] : j;
     a += work[i * 4 + 0];
     b += work[i * 4 + 1];
     c += work[i * 4 + 2];
@@ -1142,7 +1756,7 @@ __global__ void __launch_bounds__(256) mih_work_reduce_kernel(const unsigned lon
   atomicAdd(&s_t[2], c);
   __syncthreads();
   if (threadIdx.x < 3) totals[threadIdx.x] += s_t[threadIdx.x];
-  if (threadIdx.x == 3) totals[3] += nq;
+  if (threadIdx.x == 3 && count_queries) totals[3] += nq;
 }
 
 // per-query result segments of the radius search: ring[q][0 .. min(count, cap)) sorted ascending in place.
@@ -1247,6 +1861,7 @@ struct VcMihIndex {
   unsigned long long* d_totals = nullptr;   // probes | non-empty buckets | entries verified | queries
   uint64_t* d_ring = nullptr;               // [MIH_QTILE][cap] candidate rings of the multi-block shells (lazy)
   size_t ring_entries = 0;
+  size_t lds_per_block = 65536;             // hipDeviceProp.sharedMemPerBlock of the index's device
 };
 
 #define MIH_CHECK(call)                                                                                  \
@@ -1258,7 +1873,15 @@ struct VcMihIndex {
     }                                                                                                    \
   } while (0)
 
+static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits);
 static uint32_t grid_for(uint64_t n, uint32_t n_cu) { return (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)n_cu * 16); }
+
+static size_t device_lds_per_block() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 65536;
+  return prop.sharedMemPerBlock;
+}
 
 static bool g_binom_ready[16] = {};
 
@@ -1299,6 +1922,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
   VcMihIndex* ix = new VcMihIndex();
   ix->W = W; ix->m = m; ix->sbits = sbits; ix->id_base = id_base; ix->flags = flags; ix->n_cu = n_cu; ix->cap = cand_cap; ix->n = n;
   ix->knobs = knobs;
+  ix->lds_per_block = device_lds_per_block();
   ix->h_tables.resize(m);
   auto fail_free = [&](int code) { vc_mih_free(ix); return code; };
   auto dalloc = [&](void** p, size_t bytes, bool keep) -> hipError_t {
@@ -1524,7 +2148,31 @@ struct VcIndexHeader {
   char magic[8];
   uint32_t version, bits, m, sbits, id_base, reserved;
   uint64_t n;
+  uint64_t cols_checksum;   // digest of the code columns the index was built from (mih_checksum_kernel)
+  uint64_t file_bytes;      // whole file, header included: a truncated or padded file is refused
 };
+#define VC_INDEX_VERSION 2u
+
+static int cols_checksum(const uint64_t* d_cols, uint64_t stride, uint32_t W, uint64_t n, uint32_t n_cu, hipStream_t s,
+                         uint64_t* out, std::string* err) {
+  unsigned long long* d_sum = nullptr;
+  MIH_CHECK(hipMalloc((void**)&d_sum, 8));
+  hipError_t r = hipMemsetAsync(d_sum, 0, 8, s);
+  if (r == hipSuccess && n) {
+    hipLaunchKernelGGL(mih_checksum_kernel, dim3(grid_for(n * W, n_cu)), dim3(256), 0, s, d_cols, stride, W, n, d_sum);
+    r = hipGetLastError();
+  }
+  unsigned long long h = 0;
+  if (r == hipSuccess) r = hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, s);
+  if (r == hipSuccess) r = hipStreamSynchronize(s);
+  (void)hipFree(d_sum);
+  if (r != hipSuccess) {
+    if (err) *err = std::string("index checksum: ") + hipGetErrorString(r);
+    return VC_ERR_HIP;
+  }
+  *out = h;
+  return VC_OK;
+}
 static const char kIndexMagic[8] = {'V', 'C', 'M', 'I', 'H', 'I', 'D', 'X'};
 
 static int copy_out(FILE* fh, const void* d_src, size_t bytes, hipStream_t s, std::vector<char>& buf, std::string* err) {
@@ -1553,7 +2201,10 @@ static int copy_in(FILE* fh, void* d_dst, size_t bytes, hipStream_t s, std::vect
   return VC_OK;
 }
 
-int vc_mih_save(VcMihIndex* ix, const char* path, hipStream_t s, std::string* err) {
+int vc_mih_save(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, const char* path, hipStream_t s, std::string* err) {
+  uint64_t digest = 0;
+  int rc0 = cols_checksum(d_cols, stride, ix->W, ix->n, ix->n_cu, s, &digest, err);
+  if (rc0) return rc0;
   FILE* fh = fopen(path, "wb");
   if (!fh) {
     if (err) *err = std::string("Can't create file ") + path + ".";
@@ -1561,10 +2212,16 @@ int vc_mih_save(VcMihIndex* ix, const char* path, hipStream_t s, std::string* er
   }
   VcIndexHeader h{};
   memcpy(h.magic, kIndexMagic, 8);
-  h.version = 1; h.bits = ix->W * 64; h.m = ix->m; h.sbits = ix->sbits; h.id_base = ix->id_base; h.n = ix->n;
+  h.version = VC_INDEX_VERSION; h.bits = ix->W * 64; h.m = ix->m; h.sbits = ix->sbits; h.id_base = ix->id_base; h.n = ix->n;
+  h.cols_checksum = digest;
+  const uint64_t bm_words = std::max<uint64_t>((1ull << ix->sbits) / 32, 8);
+  h.file_bytes = sizeof h;
+  for (uint32_t t = 0; t < ix->m; ++t) {
+    const uint64_t off_len = ix->sbits == 32 ? (uint64_t)ix->h_tables[t].n_unique + 1 : (1ull << ix->sbits) + 1;
+    h.file_bytes += 16 + (ix->n + off_len + bm_words + (ix->sbits == 32 ? (1ull << 24) : 0)) * 4;
+  }
   int rc = fwrite(&h, sizeof h, 1, fh) == 1 ? VC_OK : VC_ERR_INVALID;
   std::vector<char> buf(32u << 20);
-  const uint64_t bm_words = std::max<uint64_t>((1ull << ix->sbits) / 32, 8);
   for (uint32_t t = 0; t < ix->m && rc == VC_OK; ++t) {
     const VcTableView& tv = ix->h_tables[t];
     const uint64_t off_len = ix->sbits == 32 ? (uint64_t)tv.n_unique + 1 : (1ull << ix->sbits) + 1;
@@ -1589,7 +2246,7 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
     return VC_ERR_INVALID;
   }
   VcIndexHeader h{};
-  if (fread(&h, sizeof h, 1, fh) != 1 || memcmp(h.magic, kIndexMagic, 8) != 0 || h.version != 1) {
+  if (fread(&h, sizeof h, 1, fh) != 1 || memcmp(h.magic, kIndexMagic, 8) != 0 || h.version != VC_INDEX_VERSION) {
     fclose(fh);
     if (err) *err = "not a verticut_gpu index file (bad magic or version)";
     return VC_ERR_INVALID;
@@ -1599,11 +2256,31 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
     if (err) *err = "index file was built for another database shape (bits / n_tables / records / id_base differ)";
     return VC_ERR_STATE;
   }
+  {   // the file must be exactly as long as its header says (truncated copies, appended garbage)
+    const long at = ftell(fh);
+    uint64_t size = 0;
+    if (at < 0 || fseek(fh, 0, SEEK_END) != 0) size = 0; else size = (uint64_t)ftell(fh);
+    if (size != h.file_bytes || fseek(fh, at, SEEK_SET) != 0) {
+      fclose(fh);
+      if (err) *err = "index file is truncated or has trailing bytes (size differs from its header)";
+      return VC_ERR_INVALID;
+    }
+  }
   int rc = upload_binom(err);
   if (rc) { fclose(fh); return rc; }
+  {   // the index must have been built from THESE records, not merely from a database of the same shape
+    uint64_t digest = 0;
+    if ((rc = cols_checksum(d_cols, stride, W, n, n_cu, s, &digest, err))) { fclose(fh); return rc; }
+    if (digest != h.cols_checksum) {
+      fclose(fh);
+      if (err) *err = "index file was built from other records than the resident ones (code checksum differs)";
+      return VC_ERR_STATE;
+    }
+  }
   VcMihIndex* ix = new VcMihIndex();
   ix->W = W; ix->m = m; ix->sbits = sbits; ix->id_base = id_base; ix->flags = flags; ix->n_cu = n_cu; ix->cap = cand_cap; ix->n = n;
   ix->knobs = knobs;
+  ix->lds_per_block = device_lds_per_block();
   ix->h_tables.resize(m);
   std::vector<char> buf(32u << 20);
   const uint64_t bm_words = std::max<uint64_t>((1ull << sbits) / 32, 8);
@@ -1646,6 +2323,59 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
       if ((rc = copy_in(fh, blockrank, (size_t)(1u << 24) * 4, s, buf, err))) break;
     }
     tv.ids = ids; tv.offsets = offsets; tv.bitmap = bitmap; tv.blockrank = blockrank; tv.n_unique = (uint32_t)th[0];
+    {   // device validation pass: see the kernels above.  Order matters: offsets and ranks first, entries last (the
+        // entry check dereferences offsets[rank(key)], which is only safe to trust once... it is bounds-checked anyway)
+      uint32_t *d_bad = nullptr, *d_seen = nullptr, *d_pop = nullptr, *d_exp = nullptr, *d_work = nullptr;
+      const uint32_t nblocks = 1u << 24;
+      hipError_t r = hipMalloc((void**)&d_bad, 4);
+      if (r == hipSuccess) r = hipMemsetAsync(d_bad, 0, 4, s);
+      if (r == hipSuccess) r = hipMalloc((void**)&d_seen, (size_t)((n + 31) / 32 + 1) * 4);
+      if (r == hipSuccess) r = hipMemsetAsync(d_seen, 0, (size_t)((n + 31) / 32 + 1) * 4, s);
+      if (r == hipSuccess) {
+        hipLaunchKernelGGL(mih_validate_offsets_kernel, dim3(grid_for(th[1], n_cu)), dim3(256), 0, s, offsets, th[1], n, d_bad);
+        r = hipGetLastError();
+      }
+      if (r == hipSuccess && sbits == 32) {
+        r = hipMalloc((void**)&d_pop, (size_t)(nblocks + 1) * 4);
+        if (r == hipSuccess) r = hipMalloc((void**)&d_exp, (size_t)nblocks * 4);
+        if (r == hipSuccess) r = hipMalloc((void**)&d_work, std::max<size_t>(vc_scan_work_words(nblocks), 64) * 4);
+        if (r == hipSuccess) {
+          hipLaunchKernelGGL(mih_blockpop_kernel, dim3(n_cu * 16), dim3(256), 0, s, bitmap, nblocks, d_pop);
+          r = hipGetLastError();
+        }
+        if (r == hipSuccess) r = vc_exclusive_scan_u32(d_pop, d_exp, nblocks, d_work, s);
+        if (r == hipSuccess) {
+          hipLaunchKernelGGL(mih_validate_rank_kernel, dim3(n_cu * 16), dim3(256), 0, s, blockrank, d_exp, d_pop, nblocks, tv.n_unique, d_bad);
+          r = hipGetLastError();
+        }
+      }
+      uint32_t bad = 0;
+      if (r == hipSuccess) r = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s);
+      if (r == hipSuccess) r = hipStreamSynchronize(s);
+      if (r == hipSuccess && bad == 0 && n) {   // directory sound: now every entry against the resident records
+        const uint32_t bitpos = t * sbits;
+        hipLaunchKernelGGL(mih_validate_entries_kernel, dim3(grid_for(n, n_cu)), dim3(256), 0, s, tv, d_cols + (uint64_t)(bitpos >> 6) * stride, n,
+                           bitpos & 63, sbits == 32 ? 0xFFFFFFFFu : (uint32_t)((1ull << sbits) - 1), sbits, d_seen, d_bad);
+        r = hipGetLastError();
+        if (r == hipSuccess) r = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s);
+        if (r == hipSuccess) r = hipStreamSynchronize(s);
+      }
+      (void)hipFree(d_bad); (void)hipFree(d_seen); (void)hipFree(d_pop); (void)hipFree(d_exp); (void)hipFree(d_work);
+      if (r != hipSuccess) {
+        if (err) *err = std::string("index validation: ") + hipGetErrorString(r);
+        rc = r == hipErrorOutOfMemory ? VC_ERR_NOMEM : VC_ERR_HIP;
+        break;
+      }
+      if (bad) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "index file is corrupt: table %u fails validation (%s%s%s%s%s)", t, bad & MIH_BAD_OFFSETS ? "offsets " : "",
+                 bad & MIH_BAD_RANK ? "rank-directory " : "", bad & MIH_BAD_ID ? "id-range " : "", bad & MIH_BAD_DUP ? "duplicate-ids " : "",
+                 bad & MIH_BAD_BUCKET ? "bucket-membership " : "");
+        if (err) *err = msg;
+        rc = VC_ERR_STATE;
+        break;
+      }
+    }
     if (sbits == 32) {   // derived directory, not in the file (see VcTableView::blockoff)
       uint32_t* blockoff = nullptr;
       if ((rc = dalloc((void**)&blockoff, ((size_t)(1u << 24) + 1) * 4))) break;
@@ -1758,8 +2488,22 @@ static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, ui
   return hipGetLastError();
 }
 
+static hipError_t launch_wave_kernel(const QueryKernelParams& p, uint32_t W, hipStream_t s) {
+  const size_t lds = mw_shared_bytes(p.m) + (size_t)(MQ_BLK / VC_WAVE) * mw_wave_bytes(p.buf_entries, W, p.m);
+  const dim3 grid((p.nq + MQ_BLK / VC_WAVE - 1) / (MQ_BLK / VC_WAVE));
+  switch (W) {
+    case 1: hipLaunchKernelGGL(mih_wave_kernel<1>, grid, dim3(MQ_BLK), lds, s, p); break;
+    case 2: hipLaunchKernelGGL(mih_wave_kernel<2>, grid, dim3(MQ_BLK), lds, s, p); break;
+    case 4: hipLaunchKernelGGL(mih_wave_kernel<4>, grid, dim3(MQ_BLK), lds, s, p); break;
+    case 8: hipLaunchKernelGGL(mih_wave_kernel<8>, grid, dim3(MQ_BLK), lds, s, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 // launch + measurement: events on the launch stream around the kernel, then the reduction of its work counters
-static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s) {
+// (wave = mih_wave_kernel over p.nq queries; otherwise mih_query_kernel over nq blocks, p.slot_list naming their slots)
+static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s, bool wave = false) {
   if (!ix->d_totals) {
     hipError_t r = hipMalloc((void**)&ix->d_totals, 32);
     if (r == hipSuccess) r = hipMemsetAsync(ix->d_totals, 0, 32, s);
@@ -1776,10 +2520,12 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p,
     if (ix->ev_used < ix->ev_pool.size()) ev = &ix->ev_pool[ix->ev_used++];
   }
   if (ev) (void)hipEventRecord(ev->first, s);
-  hipError_t r = launch_query_kernel(p, W, nq, s);
+  hipError_t r = wave ? launch_wave_kernel(p, W, s) : launch_query_kernel(p, W, nq, s);
   if (ev) (void)hipEventRecord(ev->second, s);
   if (r != hipSuccess) return r;
-  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(256), 0, s, p.st.work, nq, ix->d_totals);
+  // a continuation launch (slot_list) adds its own work to the totals but its queries were counted by the first launch
+  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(256), 0, s, p.st.work, nq, ix->d_totals, p.slot_list, p.slot_list ? 0u : 1u,
+                     p.slot_count);
   return hipGetLastError();
 }
 
@@ -1852,7 +2598,10 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   // tile (how many queries are not finished) and only those continue shell by shell through the multi-block kernels.
   uint32_t buf_entries = 1024;
   while (buf_entries < k + MQ_ROUND) buf_entries <<= 1;
-  const bool inblock = ix->knobs.mih_host_loop == 0 && buf_entries <= 8192 && ix->m <= 64;
+  // the query kernel's LDS request (top-k + candidate buffer, hit lists, binomials, masks) must fit a workgroup of this
+  // device (k = 3073..7168 asks for ~82 KB); otherwise every shell runs through the multi-block kernels
+  const bool inblock = ix->knobs.mih_host_loop == 0 && buf_entries <= 8192 && ix->m <= 64 &&
+                       query_kernel_lds(buf_entries, ix->m, S) <= ix->lds_per_block;
   if ((rc = ensure_tile(ix, k, cap, !inblock, &st, err))) return rc;
   uint32_t* lists[4] = {ix->d_lists, ix->d_lists + MIH_QTILE, ix->d_lists + 2 * MIH_QTILE, ix->d_lists + 3 * MIH_QTILE};
   uint32_t* d_ctr = ix->d_lists + 4 * MIH_QTILE;
@@ -1865,6 +2614,15 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   if (ix->knobs.mih_budget) knn_budget = ix->knobs.mih_budget;   // dev knob VC_MIH_BUDGET
   const uint32_t r_last = inblock_last_shell(S, ix->m, knn_budget, S, avg_bucket);
   const bool trace = ix->knobs.mih_trace;   // VC_MIH_TRACE: per-shell wall times on stderr
+  // mih_wave_kernel: 32-bit substrings, k small enough for a per-wave candidate buffer of 2k + one round of survivors
+  uint32_t wave_cb = 512;
+  while (wave_cb < 2 * k + MW_ROUND) wave_cb <<= 1;
+  // the wave stage runs the cheap shells only (0 and 1: 27 granules per table, one pass): a launch lasts as long as its
+  // slowest wave, and a wave that walks the 2 600 granules per table of shell 3 alone takes ~0.4 ms (measured: shells 0..3
+  // in the wave stage 7.3 M queries/s, 0..2 8.7 M, against 10.1 M for the block kernel alone)
+  uint32_t r_wave = std::min(r_last, ix->knobs.mih_wave_shells >= 0 ? (uint32_t)ix->knobs.mih_wave_shells : 1u);
+  const bool wave_ok = inblock && S == 32 && ix->knobs.mih_wave != 0 && wave_cb <= 1024 && ix->m <= 16 &&
+                       mw_shared_bytes(ix->m) + (size_t)(MQ_BLK / VC_WAVE) * mw_wave_bytes(wave_cb, ix->W, ix->m) <= ix->lds_per_block;
 
   for (uint32_t q0 = 0; q0 < nq; q0 += MIH_QTILE) {
     const uint32_t qt = std::min(MIH_QTILE, nq - q0);
@@ -1879,13 +2637,36 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0;
       const auto t_q = std::chrono::steady_clock::now();
       MIH_CHECK(hipMemsetAsync(d_ctr, 0, 16, s));
-      MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
-      MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 4, hipMemcpyDeviceToHost, s));
-      MIH_CHECK(hipStreamSynchronize(s));
-      n_heavy = n_cur = h_ctr[2];
+      if (wave_ok) {
+        // stage 1: one wave per query, shells 0..r_wave (mih_wave_kernel); stage 2: the unfinished queries continue in
+        // the block-per-query kernel (256 threads spread a big shell), shells r_wave + 1 .. r_last
+        QueryKernelParams wp = qp;
+        wp.buf_entries = wave_cb; wp.r_last = r_wave; wp.nq = qt; wp.pair01 = ix->knobs.mih_pair01 ? 1u : 0u;
+        MIH_CHECK(timed_query_launch(ix, wp, ix->W, qt, s, true));
+        if (r_wave < r_last) {
+          // launched for every query of the tile right behind stage 1; the blocks beyond the device-side count of
+          // unfinished queries leave at once -- no host round trip between the stages
+          qp.slot_list = cur; qp.slot_count = d_ctr + 2; qp.r_first = r_wave + 1; qp.heavy_list = nxt; qp.heavy_ctr = d_ctr + 3;
+          MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
+          MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 8, hipMemcpyDeviceToHost, s));
+          MIH_CHECK(hipStreamSynchronize(s));
+          if (trace) fprintf(stderr, "[vc_mih] one wave per query, shells 0..%u: %u of %u queries continue in the block kernel\n", r_wave, h_ctr[2], qt);
+          n_heavy = n_cur = h_ctr[3];
+          std::swap(cur, nxt);
+        } else {
+          MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 4, hipMemcpyDeviceToHost, s));
+          MIH_CHECK(hipStreamSynchronize(s));
+          n_heavy = n_cur = h_ctr[2];
+        }
+      } else {
+        MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
+        MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 4, hipMemcpyDeviceToHost, s));
+        MIH_CHECK(hipStreamSynchronize(s));
+        n_heavy = n_cur = h_ctr[2];
+      }
       r_start = r_last + 1;
       if (trace)
-        fprintf(stderr, "[vc_mih] shells 0..%u in one launch: %u queries, %u continue  %.1f us\n", r_last, qt, n_cur,
+        fprintf(stderr, "[vc_mih] shells 0..%u in the query kernels: %u queries, %u continue  %.1f us\n", r_last, qt, n_cur,
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_q).count());
       if (n_heavy) {
         MIH_CHECK(hipMemcpyAsync(lists[3], cur, (size_t)n_heavy * 4, hipMemcpyDeviceToDevice, s));

@@ -9,7 +9,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
                  hipStream_t s, std::string* err);
 void vc_mih_free(VcMihIndex* ix);
 // index persistence: the CSR tables + bitmaps of a built index, and back (the codes themselves travel as a code file)
-int vc_mih_save(VcMihIndex* ix, const char* path, hipStream_t s, std::string* err);
+int vc_mih_save(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, const char* path, hipStream_t s, std::string* err);
 int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t m,
                 uint32_t sbits, uint32_t id_base, uint32_t flags, uint32_t n_cu, uint32_t cand_cap, const VcKnobs& knobs,
                 hipStream_t s, std::string* err);

@@ -309,7 +309,9 @@ __device__ __forceinline__ void vc_scan_slow(const VcScanRare& p, const vc_u64x2
   uint32_t tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   uint32_t* const tau_q = p.tau + (size_t)q * p.qs;
-  uint32_t t = vc_ld_relaxed(tau_q);
+  // chip-wide threshold, never looser than the block's own (with the bootstrap folded into the prologue the chip-wide word
+  // is published by block 0 only, possibly after this wave got here)
+  uint32_t t = min(vc_ld_relaxed(tau_q), st[q]);
   const uint64_t lim = p.limit ? p.limit[q] : VC_PACK_INF;   // recovery pass: exact packed bound (ties cannot refill the ring)
   uint64_t* ring = p.buf + (uint64_t)q * p.cap;
   uint32_t* hist = p.hist + (uint64_t)q * p.hist_stride;
@@ -403,7 +405,20 @@ __global__ void __launch_bounds__(BLK, MINW ? MINW : (BLK == 512 ? 2 : ((W >= 4 
   uint64_t* sq = (uint64_t*)smem;                             // [qt][W]  query tile
   uint32_t* st = (uint32_t*)(smem + (size_t)(QT ? QT : p.qt) * W * 8);    // [qt]     block-local copy of tau (QT > 0: p.qt == QT)
   for (uint32_t i = threadIdx.x; i < p.qt * W; i += BLK) sq[i] = QT ? ~p.queries[i] : p.queries[i];
-  for (uint32_t i = threadIdx.x; i < p.qt; i += BLK) st[i] = (VC_SCAN_DIAGNOSTICS && p.wrap) ? 0u : vc_ld_relaxed(p.tau + (size_t)i * p.qs);  // wrap: rare path off
+  if (QT > 0 && p.shist) {
+    // bootstrap threshold = smallest d whose sampled cumulative count reaches k (what vc_tau_init_kernel computes); fewer
+    // than k samples = accept everything.  One wave per query; block 0 publishes the chip-wide word (cleaned to ~0).
+    for (uint32_t q = threadIdx.x / VC_WAVE; q < p.qt; q += BLK / VC_WAVE) {
+      uint32_t cut = vc_hist_cut(p.shist + (uint64_t)q * p.hist_stride, p.bits + 1, p.k, false, p.shist_copies, p.shist_cstride);
+      if (cut == 0xFFFFFFFFu) cut = p.bits;
+      if ((threadIdx.x & (VC_WAVE - 1)) == 0) {
+        st[q] = cut;
+        if (blockIdx.x == 0) atomicMin(p.tau + (size_t)q * p.qs, cut);
+      }
+    }
+  } else {
+    for (uint32_t i = threadIdx.x; i < p.qt; i += BLK) st[i] = (VC_SCAN_DIAGNOSTICS && p.wrap) ? 0u : vc_ld_relaxed(p.tau + (size_t)i * p.qs);  // wrap: rare path off
+  }
   __syncthreads();
 
   constexpr uint64_t CH = 2ull * BLK * U;
@@ -876,6 +891,8 @@ struct VcRecoverParams {
   uint32_t* clean_shist;     // clean_copies x [.. nq rows of hist_stride ..], copy stride clean_copy_stride words
   uint64_t clean_copy_stride;
   uint32_t clean_copies;     // 0 = leave the state alone
+  uint32_t spin_limit;       // bounded spin of the grid barrier, x s_sleep 32 (~0.9 us)
+  uint32_t absent;           // test knob (VC_RECOVER_TEST_FAIL): blocks the barrier waits for in vain -> forced give-up
 };
 
 // cut of a histogram plus the cumulative count below the cut bin (one wave; same result in every lane)
@@ -908,7 +925,8 @@ __device__ __forceinline__ uint32_t vc_hist_cut_below(const uint32_t* h, uint32_
 }
 
 // grid barrier with a bounded spin; false = some block gave up (every block then leaves)
-__device__ __forceinline__ bool vc_rec_barrier(uint32_t* bar, uint32_t& epoch, uint32_t* s_ok) {
+__device__ __forceinline__ bool vc_rec_barrier(uint32_t* bar, uint32_t& epoch, uint32_t* s_ok, uint32_t spin_limit,
+                                               uint32_t absent, uint32_t* gave_up) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup barrier
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -916,16 +934,13 @@ __device__ __forceinline__ bool vc_rec_barrier(uint32_t* bar, uint32_t& epoch, u
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back must have landed before the arrival shows (hipcc may drop its own wait)
     ++epoch;
     atomicAdd(&bar[0], 1u);
-    const uint32_t target = epoch * gridDim.x;
-    bool ok = true;
-    for (uint32_t spins = 0; vc_ld_relaxed(&bar[0]) < target; ++spins) {
+    const uint32_t target = epoch * (gridDim.x + absent);
+    bool ok = vc_ld_relaxed(&bar[32]) == 0;   // a block that becomes resident after the others gave up leaves at once
+    for (uint32_t spins = 0; ok && vc_ld_relaxed(&bar[0]) < target; ++spins) {
       __builtin_amdgcn_s_sleep(32);
-      if (spins > VC_REC_SPIN_LIMIT || vc_ld_relaxed(&bar[32])) {
-        ok = false;
-        break;
-      }
+      if (spins > spin_limit || vc_ld_relaxed(&bar[32])) ok = false;
     }
-    if (!ok) atomicExch(&bar[32], 1u);
+    if (!ok && atomicExch(&bar[32], 1u) == 0u) atomicAdd(gave_up, 1u);   // counted once, when the flag is first set
     __threadfence();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate completes asynchronously: hold the barrier until it has
     *s_ok = ok ? 1u : 0u;
@@ -956,19 +971,20 @@ __global__ void __launch_bounds__(256, 2) vc_recover_kernel(const VcRecoverParam
   const uint32_t n_over = s_nover;
   // Last kernel of a search step: hand the step's state back zeroed.  Nothing reads it any more once the overflow
   // list is known (no overflow), or once the last round's barriers are behind (below).
-  auto clean_state = [&]() {
+  auto clean_state = [&](bool alone) {
     if (p.clean_copies == 0) return;
-    const uint64_t gtid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t gtid = alone ? threadIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gsz = alone ? blockDim.x : (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = gtid; i < (uint64_t)p.nq * p.qs; i += gsz) {
       const_cast<uint32_t*>(p.count)[i] = 0;
-      p.clean_tau[i] = 0;
+      p.clean_tau[i] = 0xFFFFFFFFu;   // "no threshold yet": the verify prologue publishes with atomicMin
     }
     const uint64_t row = (uint64_t)p.nq * p.hist_stride;
     for (uint64_t i = gtid; i < row; i += gsz) const_cast<uint32_t*>(p.hist)[i] = 0;
     for (uint64_t i = gtid; i < row * p.clean_copies; i += gsz) p.clean_shist[(i / row) * p.clean_copy_stride + i % row] = 0;
   };
   if (n_over == 0) {
-    clean_state();
+    clean_state(false);
     return;
   }
 
@@ -978,7 +994,7 @@ __global__ void __launch_bounds__(256, 2) vc_recover_kernel(const VcRecoverParam
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)n_over * 3 * VC_REC_BINS; i += (uint64_t)gridDim.x * blockDim.x)
     p.idhist[i] = 0;
   if (blockIdx.x == 0 && threadIdx.x < n_over) p.rcount[threadIdx.x * 32] = 0;
-  alive = vc_rec_barrier(p.bar, epoch, &s_ok);
+  alive = vc_rec_barrier(p.bar, epoch, &s_ok, p.spin_limit, p.absent, p.gave_up);
 
   // position bits and the digit shifts of the (up to three) levels
   uint32_t P = 1;
@@ -1086,13 +1102,13 @@ __global__ void __launch_bounds__(256, 2) vc_recover_kernel(const VcRecoverParam
     // level 0: the whole database once for all queries of the round
     sweep(0, p.n, 0, nr, false, shifts[0], r0);
     flush(nr, r0, 0);
-    if (!(alive = vc_rec_barrier(p.bar, epoch, &s_ok))) break;
+    if (!(alive = vc_rec_barrier(p.bar, epoch, &s_ok, p.spin_limit, p.absent, p.gave_up))) break;
     locate(nr, r0, 0, shifts[0]);
     // deeper levels: only the bin that holds the need-th tie, per query
     for (uint32_t l = 1; l < nlev && alive; ++l) {
       for (uint32_t r = 0; r < nr; ++r) sweep(s_lo[r], s_lo[r] + (1ull << shifts[l - 1]), r, r + 1, false, shifts[l], r0);
       flush(nr, r0, l);
-      if (!(alive = vc_rec_barrier(p.bar, epoch, &s_ok))) break;
+      if (!(alive = vc_rec_barrier(p.bar, epoch, &s_ok, p.spin_limit, p.absent, p.gave_up))) break;
       locate(nr, r0, l, shifts[l]);
     }
     if (!alive) break;
@@ -1101,7 +1117,7 @@ __global__ void __launch_bounds__(256, 2) vc_recover_kernel(const VcRecoverParam
       s_lim[threadIdx.x] = s_need[threadIdx.x] == 0xFFFFFFFFu ? 0ull : vc_pack(s_D[threadIdx.x], p.id_base + (uint32_t)s_lo[threadIdx.x]);
     __syncthreads();
     sweep(0, p.n, 0, nr, true, 0, r0);
-    if (!(alive = vc_rec_barrier(p.bar, epoch, &s_ok))) break;
+    if (!(alive = vc_rec_barrier(p.bar, epoch, &s_ok, p.spin_limit, p.absent, p.gave_up))) break;
     // block r sorts query r's k entries into its output row
     if (blockIdx.x < nr) {
       const uint32_t r = blockIdx.x, q = s_list[r0 + r];
@@ -1120,13 +1136,23 @@ __global__ void __launch_bounds__(256, 2) vc_recover_kernel(const VcRecoverParam
       }
     }
   }
-  // the last block to leave restores the barrier words (and records a give-up once)
+  // Leaving.  Completed: every block has passed the last barrier, nobody reads the step state any more, the grid cleans
+  // it together.  Given up: blocks that only become resident now must still find the overflow (n_over > 0 above) so that
+  // they run into the barrier's give-up flag and are counted here -- so nothing is cleaned until the LAST block leaves,
+  // and that block cleans alone.  The last block also restores the barrier words.
   __syncthreads();
-  clean_state();
+  if (alive) clean_state(false);
+  __shared__ uint32_t s_last;
   if (threadIdx.x == 0) {
     __threadfence();
-    if (atomicAdd(&p.bar[64], 1u) == gridDim.x - 1) {
-      if (vc_ld_relaxed(&p.bar[32])) atomicAdd(p.gave_up, 1u);
+    s_last = atomicAdd(&p.bar[64], 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last) {
+    if (!alive) clean_state(true);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
       atomicExch(&p.bar[0], 0u);
       atomicExch(&p.bar[32], 0u);
       atomicExch(&p.bar[64], 0u);
@@ -1288,9 +1314,10 @@ hipError_t vc_launch_gather_rows(const uint64_t* cols, uint64_t stride, uint32_t
 hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t s_items,
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
                                  uint32_t k, uint32_t bits, uint32_t* d_tau, uint32_t qs, bool refine, uint32_t n_cu,
-                                 uint32_t blocks_per_cu, hipStream_t s) {
+                                 uint32_t blocks_per_cu, hipStream_t s, bool cut) {
   if (qt == 0) return hipSuccess;
-  if (s_items == 0) {   // nothing to sample: the cut of the (zero) histogram = "accept everything"
+  if (s_items == 0) {
+    if (!cut) return hipSuccess;   // the consumer cuts the (all-zero) histogram itself   // nothing to sample: the cut of the (zero) histogram = "accept everything"
     hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u, qs);
     return hipGetLastError();
   }
@@ -1314,9 +1341,16 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
   }
 #undef VC_SH_CASE
   hipError_t r = hipGetLastError();
-  if (r != hipSuccess) return r;
+  if (r != hipSuccess || !cut) return r;
   hipLaunchKernelGGL(vc_tau_init_kernel, dim3(qt), dim3(64), 0, s, d_shist, hist_stride, k, bits, d_tau, refine ? 1u : 0u, qs);
   return hipGetLastError();
+}
+
+// true when a tile of qt queries runs the small-tile form of the verify kernel (which can cut the bootstrap histograms itself)
+bool vc_scan_is_small(uint32_t W, uint32_t qt, const VcKnobs* knobs) {
+  const VcScanShape sh = vc_scan_pick_shape(W, qt, nullptr, knobs);
+  const int ud = W <= 2 ? 4 : (W <= 4 ? 2 : 1);
+  return sh.small && sh.blk == 256 && sh.dbuf == 2 && qt <= 8 && sh.unroll == ud && !VC_SCAN_DIAGNOSTICS;
 }
 
 hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, const VcKnobs* knobs,
@@ -1349,6 +1383,7 @@ hipError_t vc_launch_select_ring_list(const uint64_t* d_buf, uint32_t cap, const
   return hipGetLastError();
 }
 
+size_t vc_recover_barrier_offset_words() { return (size_t)VC_REC_MAXQ * 3 * VC_REC_BINS + (size_t)VC_REC_MAXQ * 32; }
 size_t vc_recover_scratch_words() {   // idhist | rcount lines | barrier lines (3 x 32 words) | gave_up
   return (size_t)VC_REC_MAXQ * 3 * VC_REC_BINS + (size_t)VC_REC_MAXQ * 32 + 96 + 32;
 }
@@ -1357,7 +1392,8 @@ hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, 
                              const uint64_t* d_queries, uint32_t nq, uint32_t k, uint64_t* d_ring, uint32_t cap,
                              const uint32_t* d_count, const uint32_t* d_hist, uint32_t hist_stride, uint32_t qs, uint32_t* d_scratch,
                              uint64_t* d_out, uint32_t* d_out_count, uint32_t* d_clean_tau, uint32_t* d_clean_shist,
-                             uint64_t clean_copy_stride, uint32_t clean_copies, uint32_t n_cu, hipStream_t s) {
+                             uint64_t clean_copy_stride, uint32_t clean_copies, uint32_t n_cu, uint32_t spin_limit, uint32_t absent,
+                             hipStream_t s) {
   if (nq == 0) return hipSuccess;
   if (nq > VC_REC_MAXQ) return hipErrorInvalidValue;
   VcRecoverParams p{};
@@ -1369,6 +1405,7 @@ hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, 
   p.out = d_out; p.out_count = d_out_count;
   p.nq = nq; p.k = k; p.cap = cap; p.hist_stride = hist_stride; p.qs = qs; p.bits = bits; p.id_base = id_base;
   p.clean_tau = d_clean_tau; p.clean_shist = d_clean_shist; p.clean_copy_stride = clean_copy_stride; p.clean_copies = clean_copies;
+  p.spin_limit = spin_limit ? spin_limit : VC_REC_SPIN_LIMIT; p.absent = absent;
   // block-local position histograms (32 KiB), reused as the sort buffer of the final rows (k entries, padded to a power
   // of two); kept small so that the grids of several engines fit on the chip side by side
   uint32_t kp = 2;

@@ -28,7 +28,12 @@ EXPORTS = [
     "vc_search_knn_dev", "vc_search_radius", "vc_merge_topk_dev", "vc_get_timing", "vc_set_stream",
     "vc_load_code_file", "vc_save_code_file", "vc_write_bitmap_file", "vc_device_status",
     "vc_search_radius_dev", "vc_read_bitmap_file", "vc_save_index", "vc_load_index",
+    "vc_sharded_create", "vc_sharded_destroy", "vc_sharded_last_error", "vc_sharded_exchange", "vc_sharded_add_codes",
+    "vc_sharded_add_synthetic", "vc_sharded_size", "vc_sharded_build_index", "vc_sharded_get_code", "vc_sharded_get_bucket",
+    "vc_sharded_search_knn", "vc_sharded_shard",
 ]
+MAX_SHARDS = 16
+EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL = 0, 1, 2
 
 
 class VcConfig(C.Structure):
@@ -36,6 +41,13 @@ class VcConfig(C.Structure):
         ("abi_version", C.c_uint32), ("bits", C.c_uint32), ("n_tables", C.c_uint32), ("flags", C.c_uint32),
         ("capacity", C.c_uint64), ("id_base", C.c_uint32), ("device", C.c_int32), ("cand_cap", C.c_uint32),
         ("scan_blocks", C.c_uint32), ("query_tile", C.c_uint32), ("timing_sample", C.c_uint32), ("reserved", C.c_uint32 * 4),
+    ]
+
+
+class VcShardedConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("n_shards", C.c_uint32), ("n_devices", C.c_uint32), ("exchange", C.c_uint32),
+        ("device_ids", C.c_int32 * 16), ("engine", VcConfig),
     ]
 
 
@@ -110,6 +122,19 @@ def load_library():
     L.vc_get_timing.argtypes = [vp, C.POINTER(VcTiming)]
     L.vc_set_stream.argtypes = [vp, vp]
     L.vc_device_status.argtypes = [vp, C.POINTER(u32)]
+    L.vc_sharded_create.argtypes = [C.POINTER(VcShardedConfig), C.POINTER(vp)]
+    L.vc_sharded_destroy.argtypes = [vp]
+    L.vc_sharded_last_error.restype = C.c_char_p
+    L.vc_sharded_last_error.argtypes = [vp]
+    L.vc_sharded_exchange.argtypes = [vp, C.POINTER(u32)]
+    L.vc_sharded_add_codes.argtypes = [vp, vp, u64]
+    L.vc_sharded_add_synthetic.argtypes = [vp, u64, u64, u32, u32, u32]
+    L.vc_sharded_size.argtypes = [vp, C.POINTER(u64)]
+    L.vc_sharded_build_index.argtypes = [vp]
+    L.vc_sharded_get_code.argtypes = [vp, u32, vp]
+    L.vc_sharded_get_bucket.argtypes = [vp, u32, u32, vp, vp, u32, C.POINTER(u32)]
+    L.vc_sharded_search_knn.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]
+    L.vc_sharded_shard.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     for name in EXPORTS:
         if getattr(L, name).restype is not C.c_char_p:
             getattr(L, name).restype = C.c_int
@@ -305,3 +330,97 @@ def merge_topk_dev(d_lists, n_lists, nq, k, d_out, d_counts=None, stream=None):
     rc = L.vc_merge_topk_dev(d_lists, n_lists, nq, k, d_out, d_counts, stream)
     if rc != VC_OK:
         raise VcError(rc, L.vc_last_error(None).decode())
+
+
+class ShardedEngine:
+    """The vc_sharded_* family: one process, the database split by id range over `n_shards` engines on `devices`
+    (replaces mpirun ranks + MPI gathers + the master heap, search_worker.cc:99-101,177-207)."""
+
+    def __init__(self, bits, capacity, n_shards, n_tables=0, devices=None, exchange=EXCHANGE_AUTO, flags=0, id_base=0,
+                 cand_cap=0, query_tile=0):
+        self._L = load_library()
+        self.bits, self.nbytes, self.n_shards = bits, bits // 8, n_shards
+        cfg = VcShardedConfig(abi_version=VC_ABI_VERSION, n_shards=n_shards, n_devices=len(devices or []), exchange=exchange)
+        for i, d in enumerate(devices or []):
+            cfg.device_ids[i] = d
+        cfg.engine = VcConfig(abi_version=VC_ABI_VERSION, bits=bits, n_tables=n_tables, flags=flags, capacity=capacity,
+                              id_base=id_base, device=-1, cand_cap=cand_cap, query_tile=query_tile)
+        h = C.c_void_p()
+        rc = self._L.vc_sharded_create(C.byref(cfg), C.byref(h))
+        if rc != VC_OK:
+            raise VcError(rc, self._L.vc_sharded_last_error(None).decode())
+        self._h = h
+
+    def _check(self, rc, ok=(VC_OK,)):
+        if rc not in ok:
+            raise VcError(rc, self._L.vc_sharded_last_error(self._h).decode() or self._L.vc_strerror(rc).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vc_sharded_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def exchange(self):
+        k = C.c_uint32()
+        self._check(self._L.vc_sharded_exchange(self._h, C.byref(k)))
+        return k.value
+
+    def add_codes(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self._check(self._L.vc_sharded_add_codes(self._h, _p(codes), codes.shape[0]))
+
+    def add_synthetic(self, n, seed, kind=SYNTH_UNIFORM, n_centres=0, max_flips=0):
+        self._check(self._L.vc_sharded_add_synthetic(self._h, n, seed, kind, n_centres, max_flips))
+
+    def __len__(self):
+        n = C.c_uint64()
+        self._check(self._L.vc_sharded_size(self._h, C.byref(n)))
+        return n.value
+
+    def build_index(self):
+        self._check(self._L.vc_sharded_build_index(self._h))
+
+    def get_code(self, gid):
+        out = np.empty(self.nbytes, dtype=np.uint8)
+        rc = self._check(self._L.vc_sharded_get_code(self._h, gid, _p(out)), ok=(VC_OK, VC_NOT_FOUND))
+        return out if rc == VC_OK else None
+
+    def get_bucket(self, table, index, cap=1 << 16):
+        ids = np.empty(cap, dtype=np.uint32)
+        codes = np.empty((cap, self.nbytes), dtype=np.uint8)
+        n = C.c_uint32()
+        rc = self._check(self._L.vc_sharded_get_bucket(self._h, table, index, _p(ids), _p(codes), cap, C.byref(n)),
+                         ok=(VC_OK, VC_NOT_FOUND))
+        if rc == VC_NOT_FOUND:
+            return None
+        m = min(n.value, cap)
+        return ids[:m].copy(), codes[:m].copy(), n.value
+
+    def shard_range(self, g):
+        first, cnt = C.c_uint64(), C.c_uint64()
+        self._check(self._L.vc_sharded_shard(self._h, g, None, C.byref(first), C.byref(cnt)))
+        return first.value, cnt.value
+
+    def search_knn(self, queries, k, mode=MODE_LINEAR, order=ORDER_ASCENDING, with_stats=False):
+        q = np.ascontiguousarray(queries, dtype=np.uint8)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        out = np.full((nq, k), PACK_INF, dtype=np.uint64)
+        counts = np.zeros(nq, dtype=np.uint32)
+        stats = (VcQueryStats * nq)() if with_stats else None
+        self._check(self._L.vc_sharded_search_knn(self._h, _p(q), nq, k, mode, order, _p(out), _p(counts),
+                                                  C.cast(stats, C.c_void_p) if with_stats else None))
+        if with_stats:
+            return out, counts, list(stats)
+        return out, counts

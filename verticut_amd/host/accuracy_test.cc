@@ -54,10 +54,11 @@ int main(int argc, char** argv) {
     // masked keys and min(n_tables, 4), which are exact where the reference is not.
     const char* quirks = getenv("VC_REF_QUIRKS");
     const uint32_t flags = (quirks && atoi(quirks)) ? (VC_FLAG_REF_SIGNEXT_KEYS | VC_FLAG_REF_STOP_LITERAL4) : 0u;
-    vc::Engine engine(binary_bits, binary_bits / substr_len, image_count, flags);
+    std::unique_ptr<vc::Backend> store(vc::make_backend(binary_bits, binary_bits / substr_len, image_count, flags));   // VC_SHARDS=G: several GPUs
+    vc::Backend& engine = *store;
     uint64_t loaded = 0;
-    engine.check(vc_load_code_file(engine.handle(), argv[1], image_count, &loaded));
-    engine.check(vc_build_index(engine.handle()));
+    engine.check(engine.load_code_file(argv[1], image_count, &loaded));
+    engine.check(engine.build_index());
     vc::SearchWorker worker(&engine, (int)loaded);
     FILE* f = fopen(query_file, "rb");
     if (!f) {

@@ -15,7 +15,8 @@
 //                distributed_image_search.cc:116) and print "id : dist" lines (:70-72 format);
 //                < 0: read queries from query_file (raw codes, at most 200: :83-84) and print the
 //                "Averate result" line of :87-93
-// Set VC_PRINT_RESULTS=1 to print the "id : dist" lines for file queries too; VC_REF_QUIRKS=1 reproduces the reference's
+// VC_SHARDS=G (and optionally VC_DEVICES=0,1,..) spreads the records over G GPUs of the node (vc_sharded_*), which is what
+// `mpirun -n 4` + the KV tier did for the reference.  Set VC_PRINT_RESULTS=1 to print the "id : dist" lines for file queries too; VC_REF_QUIRKS=1 reproduces the reference's
 // behaviour for substrings < 32 bit / fewer than 4 tables (sign-extended keys, literal-4 stop rule).
 // ============================================================================
 #include <stdio.h>
@@ -24,6 +25,7 @@
 
 #include <chrono>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -56,7 +58,10 @@ int main(int argc, char** argv) {
     // masked keys and min(n_tables, 4), which are exact where the reference is not.
     const char* quirks = getenv("VC_REF_QUIRKS");
     const uint32_t flags = (quirks && atoi(quirks)) ? (VC_FLAG_REF_SIGNEXT_KEYS | VC_FLAG_REF_STOP_LITERAL4) : 0u;
-    vc::Engine engine(binary_bits, binary_bits / substr_len, image_count, flags);
+    // VC_SHARDS=G [VC_DEVICES=0,1,..]: the records are split by id range over G engines (the GPUs of the node) behind the
+    // same interface; default: one engine on the current device
+    std::unique_ptr<vc::Backend> store(vc::make_backend(binary_bits, binary_bits / substr_len, image_count, flags));
+    vc::Backend& engine = *store;
     // ---- load: build_hash_tables.cc:40-70 (records in file order, id = ordinal)
     FILE* fh = fopen(code_file, "rb");
     if (!fh) {
@@ -69,11 +74,11 @@ int main(int argc, char** argv) {
       const size_t want = (size_t)std::min<uint64_t>(1u << 16, image_count - loaded);
       const size_t got = fread(buf.data(), nbytes, want, fh);
       if (got == 0) break;
-      engine.check(vc_add_codes(engine.handle(), buf.data(), got));
+      engine.check(engine.add_codes(buf.data(), got));
       loaded += got;
     }
     fclose(fh);
-    engine.check(vc_build_index(engine.handle()));
+    engine.check(engine.build_index());
 
     vc::SearchWorker worker(&engine, (int)loaded);
     uint64_t n_main_reads = 0, n_sub_reads = 0, n_local_reads = 0;

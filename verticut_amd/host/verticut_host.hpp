@@ -17,8 +17,12 @@
 // ============================================================================
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
+#include <algorithm>
 #include <list>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -86,8 +90,29 @@ class EngineError : public std::runtime_error {
   int code_;
 };
 
+// What the adapters below need from the store: one GPU (Engine) or the GPUs of a node (ShardedEngine).
+class Backend {
+ public:
+  virtual ~Backend() {}
+  virtual uint32_t bits() const = 0;
+  virtual uint32_t n_tables() const = 0;
+  uint32_t nbytes() const { return bits() / 8; }
+  virtual const char* last_error() const = 0;
+  void check(int rc) const {
+    if (rc < 0) throw EngineError(rc, last_error());
+  }
+  virtual int add_codes(const void* codes, uint64_t n) = 0;
+  virtual int load_code_file(const char* path, uint64_t max_records, uint64_t* n_read) = 0;
+  virtual int build_index() = 0;
+  virtual uint64_t size() const = 0;
+  virtual int get_code(uint32_t id, void* out) = 0;
+  virtual int get_bucket(uint32_t table, uint32_t index, uint32_t* ids, void* codes, uint32_t cap, uint32_t* n) = 0;
+  virtual int search_knn(const void* queries, uint32_t nq, uint32_t k, uint32_t mode, uint32_t order, uint64_t* out,
+                         uint32_t* counts, vc_query_stats* stats) = 0;
+};
+
 // Owns one vc_engine (one shard / GPU).
-class Engine {
+class Engine : public Backend {
  public:
   Engine(uint32_t bits, uint32_t n_tables, uint64_t capacity, uint32_t flags = 0, uint32_t id_base = 0, int device = -1) {
     vc_config c{};
@@ -103,20 +128,120 @@ class Engine {
     bits_ = bits;
     m_ = n_tables;
   }
-  ~Engine() { vc_destroy(h_); }
+  ~Engine() override { vc_destroy(h_); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
   vc_engine* handle() const { return h_; }
-  uint32_t bits() const { return bits_; }
-  uint32_t nbytes() const { return bits_ / 8; }
-  uint32_t n_tables() const { return m_; }
-  void check(int rc) const {
-    if (rc < 0) throw EngineError(rc, vc_last_error(h_));
+  uint32_t bits() const override { return bits_; }
+  uint32_t n_tables() const override { return m_; }
+  const char* last_error() const override { return vc_last_error(h_); }
+  int add_codes(const void* codes, uint64_t n) override { return vc_add_codes(h_, codes, n); }
+  int load_code_file(const char* path, uint64_t max_records, uint64_t* n_read) override { return vc_load_code_file(h_, path, max_records, n_read); }
+  int build_index() override { return vc_build_index(h_); }
+  uint64_t size() const override {
+    uint64_t n = 0;
+    vc_size(h_, &n);
+    return n;
+  }
+  int get_code(uint32_t id, void* out) override { return vc_get_code(h_, id, out); }
+  int get_bucket(uint32_t table, uint32_t index, uint32_t* ids, void* codes, uint32_t cap, uint32_t* n) override {
+    return vc_get_bucket(h_, table, index, ids, codes, cap, n);
+  }
+  int search_knn(const void* queries, uint32_t nq, uint32_t k, uint32_t mode, uint32_t order, uint64_t* out, uint32_t* counts,
+                 vc_query_stats* stats) override {
+    return vc_search_knn(h_, queries, nq, k, mode, order, out, counts, stats);
   }
  private:
   vc_engine* h_ = nullptr;
   uint32_t bits_ = 0, m_ = 0;
 };
+
+// The GPUs of one node behind the same interface (vc_sharded_*): the database split by id range into n_shards engines,
+// one exchange of per-shard top-k per batch (RCCL all-gather over xGMI, or peer copies) + the merge kernel -- what the
+// reference does with `mpirun -n 4` ranks, MPI_Gather/Gatherv/Bcast per radius and a master-side heap
+// (run_distributed_search.py:74; search_worker.cc:99-101,177-207; mpi_coordinator.cc:26-69).
+class ShardedEngine : public Backend {
+ public:
+  ShardedEngine(uint32_t bits, uint32_t n_tables, uint64_t capacity, uint32_t n_shards, const std::vector<int>& devices = {},
+                uint32_t flags = 0, uint32_t id_base = 0, uint32_t exchange = VC_EXCHANGE_AUTO) {
+    vc_sharded_config c{};
+    c.abi_version = VC_ABI_VERSION;
+    c.n_shards = n_shards;
+    c.n_devices = (uint32_t)devices.size();
+    c.exchange = exchange;
+    for (size_t i = 0; i < devices.size() && i < VC_MAX_SHARDS; ++i) c.device_ids[i] = devices[i];
+    c.engine.abi_version = VC_ABI_VERSION;
+    c.engine.bits = bits;
+    c.engine.n_tables = n_tables;
+    c.engine.capacity = capacity;
+    c.engine.flags = flags;
+    c.engine.id_base = id_base;
+    c.engine.device = -1;
+    int rc = vc_sharded_create(&c, &h_);
+    if (rc != VC_OK) throw EngineError(rc, vc_sharded_last_error(nullptr));
+    bits_ = bits;
+    m_ = n_tables;
+  }
+  ~ShardedEngine() override { vc_sharded_destroy(h_); }
+  ShardedEngine(const ShardedEngine&) = delete;
+  ShardedEngine& operator=(const ShardedEngine&) = delete;
+  vc_sharded* handle() const { return h_; }
+  uint32_t bits() const override { return bits_; }
+  uint32_t n_tables() const override { return m_; }
+  const char* last_error() const override { return vc_sharded_last_error(h_); }
+  int add_codes(const void* codes, uint64_t n) override { return vc_sharded_add_codes(h_, codes, n); }
+  int load_code_file(const char* path, uint64_t max_records, uint64_t* n_read) override {   // build_hash_tables.cc:40-70
+    FILE* fh = fopen(path, "rb");
+    if (!fh) return VC_ERR_INVALID;
+    const size_t rec = nbytes(), batch = (size_t)1 << 16;
+    std::vector<char> buf(rec * batch);
+    uint64_t total = 0;
+    int rc = VC_OK;
+    while (max_records == 0 || total < max_records) {
+      const size_t want = max_records ? (size_t)std::min<uint64_t>(batch, max_records - total) : batch;
+      const size_t got = fread(buf.data(), rec, want, fh);
+      if (got == 0) break;
+      if ((rc = vc_sharded_add_codes(h_, buf.data(), got))) break;
+      total += got;
+    }
+    fclose(fh);
+    if (n_read) *n_read = total;
+    return rc;
+  }
+  int build_index() override { return vc_sharded_build_index(h_); }
+  uint64_t size() const override {
+    uint64_t n = 0;
+    vc_sharded_size(h_, &n);
+    return n;
+  }
+  int get_code(uint32_t id, void* out) override { return vc_sharded_get_code(h_, id, out); }
+  int get_bucket(uint32_t table, uint32_t index, uint32_t* ids, void* codes, uint32_t cap, uint32_t* n) override {
+    return vc_sharded_get_bucket(h_, table, index, ids, codes, cap, n);
+  }
+  int search_knn(const void* queries, uint32_t nq, uint32_t k, uint32_t mode, uint32_t order, uint64_t* out, uint32_t* counts,
+                 vc_query_stats* stats) override {
+    return vc_sharded_search_knn(h_, queries, nq, k, mode, order, out, counts, stats);
+  }
+ private:
+  vc_sharded* h_ = nullptr;
+  uint32_t bits_ = 0, m_ = 0;
+};
+
+// VC_SHARDS=G [VC_DEVICES=0,1,...]: the drivers' switch from one engine to the sharded store (no argv position is free for
+// it: run_distributed_search.py:74-79 fixes them all)
+inline Backend* make_backend(uint32_t bits, uint32_t n_tables, uint64_t capacity, uint32_t flags) {
+  const char* g = getenv("VC_SHARDS");
+  const uint32_t shards = g ? (uint32_t)atoi(g) : 0;
+  if (shards == 0) return new Engine(bits, n_tables, capacity, flags);
+  std::vector<int> devices;
+  if (const char* d = getenv("VC_DEVICES"))
+    for (const char* p = d; *p;) {
+      devices.push_back(atoi(p));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  return new ShardedEngine(bits, n_tables, capacity, shards, devices, flags);
+}
 
 // BaseProxy over the resident index.  put(ID, BinaryCode) appends a record (ids must arrive in order, as
 // build_hash_tables.cc:55-69 produces them); put(HashIndex, Image_List) is accepted and ignored because the
@@ -124,7 +249,7 @@ class Engine {
 // bucket lists has no equivalent to perform.
 class GpuProxy : public BaseProxy<Message, Message> {
  public:
-  explicit GpuProxy(Engine* e) : e_(e) {}
+  explicit GpuProxy(Backend* e) : e_(e) {}
   int init(const char*) override { return 0; }   // pilaf_proxy.h:65-80 reads a host list; nothing to connect to here
   void close() override {}
   int contain(const Message&) override { return PROXY_NOT_FOUND; }  // unimplemented in every reference proxy too
@@ -135,12 +260,12 @@ class GpuProxy : public BaseProxy<Message, Message> {
       if (!out) return PROXY_NOT_FOUND;
       out->clear_images();
       uint32_t n = 0;
-      int rc = vc_get_bucket(e_->handle(), hi->table_id(), hi->index(), nullptr, nullptr, 0, &n);
+      int rc = e_->get_bucket(hi->table_id(), hi->index(), nullptr, nullptr, 0, &n);
       if (rc == VC_NOT_FOUND) return PROXY_NOT_FOUND;
       e_->check(rc);
       std::vector<uint32_t> ids(n);
       std::string codes((size_t)n * e_->nbytes(), '\0');
-      e_->check(vc_get_bucket(e_->handle(), hi->table_id(), hi->index(), ids.data(), &codes[0], n, &n));
+      e_->check(e_->get_bucket(hi->table_id(), hi->index(), ids.data(), &codes[0], n, &n));
       for (uint32_t i = 0; i < n; ++i) {
         ID_Code_Pair* p = out->add_images();
         p->set_id(ids[i]);
@@ -152,7 +277,7 @@ class GpuProxy : public BaseProxy<Message, Message> {
       BinaryCode* out = dynamic_cast<BinaryCode*>(&value);
       if (!out) return PROXY_NOT_FOUND;
       std::string buf(e_->nbytes(), '\0');
-      int rc = vc_get_code(e_->handle(), id->id(), &buf[0]);
+      int rc = e_->get_code(id->id(), &buf[0]);
       if (rc == VC_NOT_FOUND) return PROXY_NOT_FOUND;
       e_->check(rc);
       out->set_code(buf.data(), buf.size());
@@ -164,17 +289,16 @@ class GpuProxy : public BaseProxy<Message, Message> {
   int put(const Message& key, const Message& value) override {
     if (const ID* id = dynamic_cast<const ID*>(&key)) {
       const BinaryCode* c = dynamic_cast<const BinaryCode*>(&value);
-      uint64_t n = 0;
-      vc_size(e_->handle(), &n);
+      const uint64_t n = e_->size();
       if (!c || c->code().size() != e_->nbytes() || id->id() != n) return PROXY_PUT_FAIL;
-      return vc_add_codes(e_->handle(), c->code().data(), 1) == VC_OK ? PROXY_PUT_DONE : PROXY_PUT_FAIL;
+      return e_->add_codes(c->code().data(), 1) == VC_OK ? PROXY_PUT_DONE : PROXY_PUT_FAIL;
     }
     if (dynamic_cast<const HashIndex*>(&key)) return PROXY_PUT_DONE;
     return PROXY_PUT_FAIL;
   }
 
  private:
-  Engine* e_;
+  Backend* e_;
 };
 
 // ---- src/search_worker.h:18-64
@@ -187,7 +311,7 @@ class SearchWorker {
 
   // The reference takes (mpi_coordinator*, BaseProxy*, image_total); the coordinator is gone (all tables
   // live in one HBM), the proxy's engine is what is searched.
-  SearchWorker(Engine* engine, int image_total) : e_(engine), image_total_(image_total) {}
+  SearchWorker(Backend* engine, int image_total) : e_(engine), image_total_(image_total) {}
 
   // search_worker.cc:65-89.  approximate -> search_K_approximate_nearest_neighbors (:93-157),
   // else search_K_nearest_neighbors (:159-218).  Farthest first, like the reference's heap drain.
@@ -197,8 +321,8 @@ class SearchWorker {
     result_.clear();
     std::vector<uint64_t> out((size_t)knn);
     uint32_t cnt = 0;
-    e_->check(vc_search_knn(e_->handle(), binary_code, 1, (uint32_t)knn, approximate ? VC_MODE_MIH_APPROX : VC_MODE_MIH_EXACT,
-                            VC_ORDER_FARTHEST_FIRST, out.data(), &cnt, &stat_));
+    e_->check(e_->search_knn(binary_code, 1, (uint32_t)knn, approximate ? VC_MODE_MIH_APPROX : VC_MODE_MIH_EXACT,
+                             VC_ORDER_FARTHEST_FIRST, out.data(), &cnt, &stat_));
     for (uint32_t i = 0; i < cnt; ++i) result_.push_back({(uint32_t)(out[i] & 0xffffffffu), (uint32_t)(out[i] >> 32)});
     return result_;
   }
@@ -215,15 +339,14 @@ class SearchWorker {
   std::list<search_result_st> linear_search(const char* binary_code, int knn) {
     std::vector<uint64_t> out((size_t)knn);
     uint32_t cnt = 0;
-    e_->check(vc_search_knn(e_->handle(), binary_code, 1, (uint32_t)knn, VC_MODE_LINEAR, VC_ORDER_FARTHEST_FIRST, out.data(),
-                            &cnt, nullptr));
+    e_->check(e_->search_knn(binary_code, 1, (uint32_t)knn, VC_MODE_LINEAR, VC_ORDER_FARTHEST_FIRST, out.data(), &cnt, nullptr));
     std::list<search_result_st> r;
     for (uint32_t i = 0; i < cnt; ++i) r.push_back({(uint32_t)(out[i] & 0xffffffffu), (uint32_t)(out[i] >> 32)});
     return r;
   }
 
  private:
-  Engine* e_;
+  Backend* e_;
   int image_total_;
   std::list<search_result_st> result_;
   vc_query_stats stat_{};
@@ -232,14 +355,14 @@ class SearchWorker {
 // ---- src/image_search_client.h:12-27 (served in process: image_search_server.cc:22-102 without ssh/popen)
 class image_search_client {
  public:
-  explicit image_search_client(Engine* engine) : e_(engine), worker_(engine, 0) {}
+  explicit image_search_client(Backend* engine) : e_(engine), worker_(engine, 0) {}
   std::string ping(const std::string& s) { return s; }   // image_search_server.cc:51-53 echoes the string
   // (image id, distance) pairs in the order the worker prints them ("id : dist" lines, farthest first).
   // The by-id path is dead in the reference as shipped (distributed_image_search.cc:116); here the code of
   // image `id` is read back from the resident DB and searched.
   std::list<std::pair<uint32_t, uint32_t> > search_image_by_id(uint32_t id, int knn, bool approximate = false) {
     std::string code(e_->nbytes(), '\0');
-    int rc = vc_get_code(e_->handle(), id, &code[0]);
+    int rc = e_->get_code(id, &code[0]);
     if (rc == VC_NOT_FOUND) throw EngineError(VC_NOT_FOUND, "Can't find match");   // distributed_image_search.cc:98
     e_->check(rc);
     std::list<std::pair<uint32_t, uint32_t> > out;
@@ -247,7 +370,7 @@ class image_search_client {
     return out;
   }
  private:
-  Engine* e_;
+  Backend* e_;
   SearchWorker worker_;
 };
 

@@ -61,11 +61,41 @@ class GpuBackend:
         self.engine.close()
 
 
+class PendingResult:
+    """What a bucketed search() returns: the rows of one batch whose exchange happens with its bucket.
+
+    get() -> (packed[nq, k] int64, counts[nq] int32), views into the bucket's buffers, enqueued-complete on the caller's
+    stream; it exchanges the (partly filled) bucket first if that has not happened yet.  A bucket's buffers are reused by
+    the bucket after the next one (two buffer sets alternate), so a handle must be consumed before two further buckets
+    have been exchanged -- get() raises afterwards instead of returning recycled memory."""
+
+    def __init__(self, owner, gen, lo, hi, bufs):
+        self._owner, self._gen, self._lo, self._hi, self._bufs = owner, gen, lo, hi, bufs
+
+    @property
+    def ready(self):
+        """the bucket's all-gather + merge have been enqueued (the tensors are valid in stream order)"""
+        return self._owner._exchanged >= self._gen
+
+    def get(self):
+        o = self._owner
+        if o._exchanged < self._gen:
+            o.flush()
+        if o._gen - self._gen >= 2 and o._fill_gen_started(self._gen + 2):
+            raise RuntimeError("PendingResult consumed too late: its bucket buffers have been reused by a later bucket")
+        out, ocnt = self._bufs
+        return out[self._lo:self._hi], ocnt[self._lo:self._hi]
+
+    def __iter__(self):            # `out, cnt = ss.search(...)` keeps working: unpacking waits for the bucket
+        return iter(self.get())
+
+
 class ShardedSearch:
     """k-NN over a database split across the ranks of `group` (default: WORLD).
 
     search(queries[nq, bits/8] uint8 on this rank's device, k) -> (packed[nq, k] int64 (bit pattern of the
-    uint64 dist<<32|id, ascending, -1 = padding), counts[nq] int32), identical on every rank.
+    uint64 dist<<32|id, ascending, -1 = padding), counts[nq] int32), identical on every rank; with bucket > 1 a
+    PendingResult handle whose get() returns that pair (it also unpacks like the pair).
     """
 
     def __init__(self, bits, total_n, rank=None, world=None, n_tables=0, device=None, group=None, backend=None,
@@ -73,12 +103,16 @@ class ShardedSearch:
         """pipelined=True: the all-gather + merge of batch i run on a side stream while batch i+1 is already being
         scanned; results of a call are then ordered on the caller's stream only after flush() (or two calls later).
         bucket=B > 1: the per-shard top-k of B consecutive batches are exchanged with ONE all-gather + merge (the
-        collective is latency-bound at 6.4 KB per rank, so B batches cost the same as one); the tensors a call returns
-        are filled in when its bucket is exchanged -- after B - 1 more calls, or flush() -- and reused by the next bucket."""
+        collective is latency-bound at 6.4 KB per rank, so B batches cost the same as one); search() then returns a
+        PendingResult whose get() yields the tensors once the bucket has been exchanged (after B - 1 more calls, or at
+        flush(), or on demand)."""
         self.group = group
         self.bucket = max(1, int(bucket))
         self._fill = 0
         self._bkey = None
+        self._bsets = [None, None]     # two buffer sets alternate between bucket generations
+        self._gen = 0                  # generation of the bucket being filled
+        self._exchanged = -1           # last generation whose exchange has been enqueued
         self.pipelined = pipelined
         self.force_exchange = force_exchange   # run the all-gather + merge even with one rank (exercises RCCL on 1 GPU)
         self._side = None
@@ -161,6 +195,9 @@ class ShardedSearch:
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
 
+    def _fill_gen_started(self, gen):
+        return self._gen > gen or (self._gen == gen and self._fill > 0)
+
     def _exchange_bucket(self):
         _, nq, k, local, lcnt, gath, out, ocnt = self._bkey
         rows = self._fill * nq
@@ -168,25 +205,36 @@ class ShardedSearch:
         g = gath.view(-1, k)[: self.world * rows]                       # [world][rows][k], contiguous prefix
         dist.all_gather_into_tensor(g, local[:rows], group=self.group)   # rank-major concat
         self.backend.merge(g.view(self.world, rows, k), self.world, rows, k, out[:rows], ocnt[:rows])
+        self._exchanged = self._gen
+        self._gen += 1
+        self._bkey = None                                                # the next bucket takes the other buffer set
+
+    def _bucket_buffers(self, key, nq, k, dev):
+        j = self._gen & 1
+        if self._bsets[j] is None or self._bsets[j][0] != key:
+            B = self.bucket
+            self._bsets[j] = (key, nq, k, torch.empty((B * nq, k), dtype=torch.int64, device=dev),
+                              torch.empty((B * nq,), dtype=torch.int32, device=dev),
+                              torch.empty((self.world, B * nq, k), dtype=torch.int64, device=dev),
+                              torch.empty((B * nq, k), dtype=torch.int64, device=dev),
+                              torch.empty((B * nq,), dtype=torch.int32, device=dev))
+        return self._bsets[j]
 
     def _search_bucketed(self, queries, k, mode):
         nq, dev, B = queries.shape[0], queries.device, self.bucket
         key = (nq, k, str(dev), mode)
-        if self._bkey is None or self._bkey[0] != key:
-            if self._fill:
-                self._exchange_bucket()                                   # shape changed mid-bucket
-            self._bkey = (key, nq, k, torch.empty((B * nq, k), dtype=torch.int64, device=dev),
-                          torch.empty((B * nq,), dtype=torch.int32, device=dev),
-                          torch.empty((self.world, B * nq, k), dtype=torch.int64, device=dev),
-                          torch.empty((B * nq, k), dtype=torch.int64, device=dev),
-                          torch.empty((B * nq,), dtype=torch.int32, device=dev))
+        if self._bkey is not None and self._bkey[0] != key and self._fill:
+            self._exchange_bucket()                                       # shape changed mid-bucket
+        if self._bkey is None:
+            self._bkey = self._bucket_buffers(key, nq, k, dev)
         _, _, _, local, lcnt, gath, out, ocnt = self._bkey
         lo, hi = self._fill * nq, (self._fill + 1) * nq
         self.backend.local_topk(queries, k, local[lo:hi], lcnt[lo:hi], mode)
         self._fill += 1
+        res = PendingResult(self, self._gen, lo, hi, (out, ocnt))
         if self._fill == B:
             self._exchange_bucket()
-        return out[lo:hi], ocnt[lo:hi]
+        return res
 
     def search(self, queries, k, mode=vc.MODE_LINEAR):
         exchange = self.world > 1 or self.force_exchange
