@@ -333,7 +333,7 @@ def run_headline(args, env, emit, backend_factory=None):
         for i in range(count):
             res = ss.search(dev_q[i % nb], k)
         ss.flush()                  # N > 1: the last (partly filled) bucket is exchanged inside the timed region
-        return res
+        return res.get() if hasattr(res, "get") else res    # bucketed exchange hands out PendingResult handles
 
     # Priming, part of set-up like the data generation above: the first launches after the 16 GB fill run 10-15 %
     # slow (clocks, page tables; kernel trace in profiles/), and a driver-chosen --warmup may be shorter than that.
@@ -452,7 +452,7 @@ def _near_queries(engine, n, nq, bits, max_flips, rng):
     return q
 
 
-def _mih_roofline(tm, bits):
+def _mih_roofline(tm, bits, kernel="mih_query_kernel"):
     """bytes = probes x 4 (bitmap) + non-empty buckets x 16 (key lookup) + entries x (4 id + B/8 code)"""
     if tm.mih_launches == 0:
         return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
@@ -464,7 +464,7 @@ def _mih_roofline(tm, bits):
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     return {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-        "traffic": None, "kernel": "mih_query_kernel", "launches": tm.mih_launches, "avg_launch_ms": avg_ms,
+        "traffic": None, "kernel": kernel, "launches": tm.mih_launches, "avg_launch_ms": avg_ms,
         "algorithmic_bytes_per_launch": alg,
         "per_query": {"probes": tm.mih_probes / max(tm.mih_queries, 1), "non_empty_buckets": tm.mih_hits / max(tm.mih_queries, 1),
                       "entries_verified": tm.mih_entries / max(tm.mih_queries, 1)},
@@ -627,7 +627,8 @@ def run_c2(args, env, emit):
             if not ok:
                 sys.stderr.write("[bench] c2 m=%d: MIH result differs from the linear scan\n" % m)
         lines[m] = {
-            "value": Q * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "roofline": _mih_roofline(tm, bits),
+            "value": Q * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+            "roofline": _mih_roofline(tm, bits, "mih_bucket_stream_kernel" if bits // m <= 16 else "mih_query_kernel"),
             "index_build_s": t_build, "mean_neighbours": float(d_off[Q].item()) / Q, "results_check": "ok" if ok else "FAILED",
         }
         e.close()

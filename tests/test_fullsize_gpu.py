@@ -223,3 +223,29 @@ def test_mih_exact_top100_over_1e9_clustered_codes_128bit(vc, oracle):
             exp = oracle.linear_knn_slabbed(pool, n, bits, 34, q[sel], k, kind=1, n_centres=nc, max_flips=mf)
         assert np.array_equal(lin[sel], exp)                                        # the HIP scan IS the oracle's row
         assert np.array_equal(got[sel] >> SH, exp >> SH)
+
+
+def test_config2_m4_variant_streams_its_buckets_over_1e8_codes(vc, oracle):
+    """BASELINE configs[1] with the reference's default table count: 64-bit codes in m = 4 substrings of 16 bit, buckets of
+    ~1 526 entries each -- the radius-8 search streams 188 buckets per query from the bucket-order code copies
+    (mih_bucket_stream_kernel).  MIH == HIP scan for all queries, == the oracle's brute force over the same 1e8 codes."""
+    n, bits, m, radius = 100_000_000, 64, 4, 8
+    rng = np.random.default_rng(24)
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_synthetic(n, seed=34)
+        e.build_index()
+        plant = [int(x) for x in rng.integers(0, n, size=24)]
+        nflip = [int(x) for x in rng.integers(0, radius + 1, size=24)]
+        q = np.stack([_flip(e.get_code(g), rng.choice(bits, size=f, replace=False), rng) for g, f in zip(plant, nflip)])
+        mih = e.search_radius(q, radius, mode=vc.MODE_MIH_EXACT)
+        t = e.timing()
+        assert t.mih_launches >= 1 and t.mih_entries > 24 * 150_000       # ~287 K bucket entries per query were streamed
+        lin = e.search_radius(q, radius, mode=vc.MODE_LINEAR)
+        for i, (g, f) in enumerate(zip(plant, nflip)):
+            assert np.array_equal(mih[i], lin[i])
+            assert (np.uint64(f) << SH) | np.uint64(g) in mih[i]
+        sel = [0, 5, 11, 23]
+        with oracle.Pool() as pool:
+            exp = oracle.linear_radius_slabbed(pool, n, bits, 34, q[sel], radius)
+        for j, i in enumerate(sel):
+            assert np.array_equal(mih[i], exp[j])

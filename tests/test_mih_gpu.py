@@ -480,3 +480,49 @@ def test_radius_larger_than_the_probe_budget_falls_back_to_the_scan(vc, oracle):
                 ids = np.nonzero(d <= radius)[0]
                 assert np.array_equal(rad[i], np.sort(oracle.pack(d[ids], ids.astype(np.uint64))))
         assert len(rad[0]) == n                              # radius = bits: everything
+
+
+@pytest.mark.parametrize("bits,m,fl", [(64, 4, ""), (64, 4, "signext"), (64, 8, ""), (128, 8, "")])
+def test_radius_search_through_the_bucket_streaming_kernel(vc, oracle, monkeypatch, bits, m, fl):
+    """<= 16-bit substrings whose shells exceed the query kernel's entry budget stream their buckets from the bucket-order
+    code copies (mih_bucket_stream_kernel); VC_MIH_STREAM=2 sends small databases through it too.  Every radius around
+    a query with neighbours at every distance (all pigeonhole remainders), near-duplicate queries on clustered data,
+    duplicate-heavy buckets with 20 000+ neighbours (ring growth + repeat), the sign-extended-key quirk; against numpy
+    and the oracle's restatement of search_R_neighbors (search_worker.cc:222-264)."""
+    monkeypatch.setenv("VC_MIH_STREAM", "2")
+    signext = fl == "signext"
+    flags = vc.FLAG_REF_SIGNEXT_KEYS if signext else 0
+    n = 30000
+    rng = np.random.default_rng(bits + m + len(fl))
+    base = oracle.gen_codes(1, bits, 5)[0]
+    codes = np.tile(base, (n, 1))
+    for i in range(n):
+        for b in rng.choice(bits, size=int(rng.integers(0, 2 * m + 4)), replace=False):
+            codes[i, b // 8] ^= np.uint8(1 << (b % 8))
+    q = base[None, :].copy()
+    d = oracle.np_distances(codes, q[0])
+    mo = oracle.MihOracle(codes, m, key_mode=0 if signext else 1)
+    with vc.Engine(bits, capacity=n, n_tables=m, flags=flags) as e:
+        e.add_codes(codes)
+        e.build_index()
+        for radius in range(0, 2 * m + 3):
+            mih = e.search_radius(q, radius, mode=vc.MODE_MIH_EXACT, cap_per_query=1 << 15)
+            ores, _ = mo.radius(q[0], radius)
+            assert np.array_equal(mih[0], ores), (radius, len(mih[0]), len(ores))
+            if not signext:                      # masked keys are exact: == brute force
+                ids = np.nonzero(d <= radius)[0]
+                assert np.array_equal(mih[0], np.sort(oracle.pack(d[ids], ids.astype(np.uint64))))
+        t = e.timing()
+        assert t.mih_launches > 0 and t.mih_entries > 0 and t.mih_probes > 0      # the streaming kernel is instrumented
+    # clustered data, several queries per call, a small batch (the probe list is split over blocks) and a big one
+    codes = oracle.gen_codes(60000, bits, 34, kind=1, n_centres=40, max_flips=6)
+    with vc.Engine(bits, capacity=len(codes), n_tables=m, flags=flags) as e:
+        e.add_codes(codes)
+        e.build_index()
+        mo = oracle.MihOracle(codes, m, key_mode=0 if signext else 1)
+        for nq in (3, 700):
+            qq = _near_queries(codes, nq, rng, 3)
+            mih = e.search_radius(qq, m + 2, mode=vc.MODE_MIH_EXACT, cap_per_query=4096)
+            for i in range(0, nq, max(1, nq // 25)):
+                ores, _ = mo.radius(qq[i], m + 2)
+                assert np.array_equal(mih[i], ores), (nq, i)

@@ -59,13 +59,15 @@ def _worker(rank, world, port, total_n, bits, k, ret):
     held = []
     for r in range(5):
         qq = np.roll(q, r, axis=0).copy()
-        held.append((r, sb.search(torch.from_numpy(qq).cuda(), k)[0]))
+        held.append((r, sb.search(torch.from_numpy(qq).cuda(), k)))      # PendingResult handles
         if r == 2 or r == 4:
+            ok = ok and all(h.ready for _, h in held) == (r == 2)          # the third call exchanged its bucket; 4 and 5 wait
             if r == 4:
                 sb.flush()
             torch.cuda.synchronize()
-            for rr, o in held:
-                ok = ok and bool(np.array_equal(o.cpu().numpy().view(np.uint64), np.roll(exp, rr, axis=0)))
+            for rr, h in held:
+                o, c = h.get()
+                ok = ok and bool(np.array_equal(o.cpu().numpy().view(np.uint64), np.roll(exp, rr, axis=0))) and bool(np.all(c.cpu().numpy() == k))
             held = []
     ret[rank] = ok
     ss.close()

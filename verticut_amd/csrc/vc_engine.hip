@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 
 #include "vc_internal.hpp"
 #include "vc_mih.hpp"
@@ -29,9 +30,15 @@ struct vc_engine {
   uint64_t* d_ring = nullptr;   size_t ring_bytes = 0;    // per tile: [qt][cap]
   uint64_t* d_out = nullptr;    size_t out_bytes = 0;     // [nq][k]
   uint32_t* d_cnt = nullptr;    size_t cnt_bytes = 0;     // [nq] result counts | [nq] raw ring counts
+  // exact-MIH cost-model switch (mih_scan_fallback): gathered queries, their scan rows / counts / settled flags
+  uint64_t* d_fq = nullptr;     size_t fq_bytes = 0;
+  uint64_t* d_frows = nullptr;  size_t frows_bytes = 0;
+  uint32_t* d_fcnt = nullptr;   size_t fcnt_bytes = 0;
   uint32_t* d_rec = nullptr;                              // scratch of the device-side ring-overflow recovery (zero at first use)
   // the last kernel of a linear step (vc_recover_kernel) hands the per-step state back zeroed: no memset per step
   const uint32_t* clean_ptr = nullptr;  size_t clean_words = 0;
+  uint64_t clean_layout = 0;                              // (queries per group, histogram stride) the clean state is laid out for:
+                                                          // the threshold lines are "clean" at ~0, everything else at 0
   uint32_t scan_event_tick = 0;                           // VC_FLAG_LEAN_TIMING: only every timing_sample-th verify launch is timed
   VcKnobs knobs;                                          // environment knobs, read once at vc_create
   uint32_t recover_sabotage = 0;                          // test knob VC_RECOVER_TEST_FAIL: recover launches still to be made to give up
@@ -109,6 +116,8 @@ static void read_knobs(VcKnobs* k) {
   if (const char* v = getenv("VC_SCAN_SMALL")) k->scan_small = atoi(v);
   if (const char* v = getenv("VC_MIH_BUDGET")) k->mih_budget = strtoull(v, nullptr, 10);
   if (const char* v = getenv("VC_TAU_FOLD")) k->tau_fold = atoi(v);
+  if (const char* v = getenv("VC_MIH_STREAM")) k->mih_stream = atoi(v);
+  if (const char* v = getenv("VC_MIH_SWITCH")) k->mih_switch = atoi(v);
   if (const char* v = getenv("VC_MIH_WAVE")) k->mih_wave = atoi(v);
   if (const char* v = getenv("VC_MIH_WAVE_SHELLS")) k->mih_wave_shells = atoi(v);
   if (const char* v = getenv("VC_MIH_PAIR01")) k->mih_pair01 = atoi(v);
@@ -259,6 +268,9 @@ int vc_destroy(vc_engine* e) {
   (void)hipFree(e->d_out);
   (void)hipFree(e->d_cnt);
   (void)hipFree(e->d_rec);
+  (void)hipFree(e->d_fq);
+  (void)hipFree(e->d_frows);
+  (void)hipFree(e->d_fcnt);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->last_call) (void)hipEventDestroy(e->last_call);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -650,7 +662,9 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
 
 // d_q: [nq][W] words on the device.  Results: d_out [nq][k] ascending (INF padded), d_cnt[0..nq) counts
 // (UINT32_MAX == the ring overflowed, the device-side recovery did not run or gave up, and the row is only an upper bound).
-static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_cnt) {
+typedef std::function<int(uint32_t g0, uint32_t gq, const LinearBufs& b)> LinearHook;
+static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t k, uint64_t* d_out, uint32_t* d_cnt,
+                        const LinearHook* after_select = nullptr) {
   LinearBufs b;
   int rc = linear_bufs(e, nq, k, &b);
   if (rc) return rc;
@@ -671,7 +685,8 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
     const uint32_t gq = std::min(b.GQ, nq - g0);
     const uint64_t* dg = d_q + (size_t)g0 * e->W;
     // per-step state: zero from the previous step's last kernel, or (first use, new buffer, after an error) memset now
-    const bool clean = e->knobs.device_recover && e->clean_ptr == e->d_state && e->clean_words >= b.state_words;
+    const uint64_t layout = ((uint64_t)b.GQ << 32) | b.hs;
+    const bool clean = e->knobs.device_recover && e->clean_ptr == e->d_state && e->clean_words >= b.state_words && e->clean_layout == layout;
     e->clean_ptr = nullptr;
     if (!clean) {
       VC_HIP(e, hipMemsetAsync(e->d_state, 0, e->state_bytes, e->stream));
@@ -691,6 +706,8 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
                           fold ? b.d_shist + (size_t)t0 * b.hs : nullptr, (uint64_t)gq * b.hs))) return rc;
     VC_HIP(e, vc_launch_select_ring(e->d_ring, b.cap, b.d_count, b.d_tau, VC_QUERY_LINE_WORDS, gq, k, d_out + (size_t)g0 * k,
                                     d_cnt + g0, e->stream));
+    // (the exact-MIH switch replays the radius loop's stop rule here: rings and cursors of the group are still intact)
+    if (after_select && (rc = (*after_select)(g0, gq, b))) return rc;
     // rows whose ring overflowed (count reported as UINT32_MAX) are recomputed exactly on the device: a no-op launch otherwise
     if (e->knobs.device_recover)
       for (uint32_t c0 = 0; c0 < gq; c0 += 64)   // one launch serves 64 queries (a group is larger only when one tile is: query_tile > 64)
@@ -705,6 +722,7 @@ static int linear_batch(vc_engine* e, const uint64_t* d_q, uint32_t nq, uint32_t
     if (e->knobs.device_recover && !sample2) {
       e->clean_ptr = e->d_state;
       e->clean_words = e->state_bytes / 4;
+      e->clean_layout = layout;
     }
   }
   return VC_OK;
@@ -806,6 +824,39 @@ static int linear_recover(vc_engine* e, const uint64_t* d_q, uint32_t k, const s
   return VC_OK;
 }
 
+// Cost-model switch of the exact MIH k-NN loop (VcMihScanFallback, vc_mih.hpp): the listed queries are answered by the
+// verify kernel in HBM-bound tiles of 8 and the stop rule of search_worker.cc:201-205 is replayed on each tile's
+// candidates (mih_replay_kernel) between the select and the recover launch; with statistics wanted, one more pass over
+// the shard counts the items the radius loop would have verified (minimum substring distance <= radius).
+static int mih_scan_fallback(void* ctx, const uint64_t* d_q, const uint32_t* d_list, uint32_t n, uint32_t k, uint32_t stop_mult,
+                             const VcMihScanTarget& tgt, bool want_stats, uint32_t* d_unresolved, uint32_t* d_n_unresolved, hipStream_t s) {
+  vc_engine* e = (vc_engine*)ctx;
+  int rc;
+  if ((rc = grow(e, &e->d_fq, &e->fq_bytes, (size_t)n * e->W * 8))) return rc;
+  if ((rc = grow(e, &e->d_frows, &e->frows_bytes, (size_t)n * k * 8))) return rc;
+  if ((rc = grow(e, &e->d_fcnt, &e->fcnt_bytes, (size_t)n * 8))) return rc;
+  uint32_t* d_flag = e->d_fcnt + n;
+  VC_HIP(e, vc_launch_gather_queries(d_q, d_list, n, e->W, e->d_fq, s));
+  const LinearHook hook = [&](uint32_t g0, uint32_t gq, const LinearBufs& b) -> int {
+    VcMihReplayArgs a{};
+    a.lin_ring = e->d_ring; a.lin_count = b.d_count; a.rows = e->d_frows + (size_t)g0 * k; a.rows_cnt = e->d_fcnt + g0;
+    a.queries = e->d_fq + (size_t)g0 * e->W; a.list = d_list + g0; a.cols = e->d_cols; a.stride = e->stride;
+    a.lin_cap = b.cap; a.lin_qs = VC_QUERY_LINE_WORDS; a.gq = gq; a.k = k; a.m = e->m; a.sbits = e->sbits; a.W = e->W;
+    a.stop_mult = stop_mult; a.id_base = e->cfg.id_base; a.tgt = tgt; a.unresolved = d_unresolved; a.n_unresolved = d_n_unresolved;
+    a.resolved_flag = d_flag + g0;
+    VC_HIP(e, vc_launch_mih_replay(a, s));
+    return VC_OK;
+  };
+  const uint32_t saved_tile = e->qtile;
+  e->qtile = 8;                                   // HBM-bound passes
+  rc = linear_batch(e, e->d_fq, n, k, e->d_frows, e->d_fcnt, &hook);
+  e->qtile = saved_tile;
+  if (rc) return rc;
+  if (want_stats)
+    VC_HIP(e, vc_launch_minsub_count(e->d_cols, e->stride, e->n, e->W, e->m, e->sbits, e->d_fq, d_list, d_flag, n, tgt.radius, tgt.seen, e->n_cu, s));
+  return VC_OK;
+}
+
 static int check_knn_args(vc_engine* e, const void* q, uint32_t nq, uint32_t k, uint32_t mode) {
   if (!e || !q || nq == 0) return VC_ERR_INVALID;
   if (k == 0 || k > VC_MAX_K) return fail(e, VC_ERR_INVALID, "k must be in 1..%u", VC_MAX_K);
@@ -827,8 +878,9 @@ int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t
   if (mode == VC_MODE_LINEAR) {
     rc = linear_batch(e, (const uint64_t*)d_queries, nq, k, d_out, d_counts ? d_counts : e->d_cnt);
   } else {
+    const VcMihScanFallback fb{mih_scan_fallback, e, e->n_cu};
     rc = vc_mih_search(e->mih, e->d_cols, e->stride, e->n, (const uint64_t*)d_queries, nq, k, mode == VC_MODE_MIH_APPROX,
-                       d_out, d_counts ? d_counts : e->d_cnt, nullptr, e->stream, &e->err);
+                       d_out, d_counts ? d_counts : e->d_cnt, nullptr, e->stream, &e->err, &fb);
   }
   timing_end(e);
   e->stream = saved;
@@ -853,8 +905,9 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
     rc = linear_batch(e, e->d_q, nq, k, e->d_out, e->d_cnt);
   } else {
     st.resize(nq);
+    const VcMihScanFallback fb{mih_scan_fallback, e, e->n_cu};
     rc = vc_mih_search(e->mih, e->d_cols, e->stride, e->n, e->d_q, nq, k, mode == VC_MODE_MIH_APPROX, e->d_out,
-                       e->d_cnt, st.data(), e->stream, &e->err);
+                       e->d_cnt, st.data(), e->stream, &e->err, &fb);
   }
   timing_end(e);
   if (rc) return rc;

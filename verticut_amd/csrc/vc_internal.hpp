@@ -22,7 +22,10 @@ struct VcKnobs {
   int resident_mb = -1;                       // VC_SCAN_RESIDENT_MB: database prefix kept in the Infinity Cache by the verify pass (-1 = default)
   bool scan_trace = false;                    // VC_SCAN_TRACE=1 (diagnostic build): per-block start / end times of the verify kernel
   int mih_host_loop = 0;                      // VC_MIH_HOST_LOOP=1: one host round trip per shell (the round-1 loop)
-  int tau_fold = 1;                           // VC_TAU_FOLD=0: thresholds by vc_tau_init_kernel even for small tiles
+  int mih_switch = 1;                         // VC_MIH_SWITCH=0: the exact k-NN loop never switches to the verify kernel; 2: always (tests)
+  int mih_stream = 1;                         // VC_MIH_STREAM=0: radius search over <= 16-bit substrings through the per-shell probe kernels
+  int tau_fold = 0;                           // VC_TAU_FOLD=1: small tiles cut the bootstrap histograms in the verify prologue instead of a
+                                              // vc_tau_init_kernel launch (measured: the 1024 prologues cost 20 us, the launch 5 -- off)
   int mih_wave = 1;                           // VC_MIH_WAVE=0: k-NN through the block-per-query kernel only (no mih_wave_kernel stage)
   int mih_wave_shells = -1;                   // VC_MIH_WAVE_SHELLS: last shell run by mih_wave_kernel (-1 = automatic)
   int mih_pair01 = 1;                         // VC_MIH_PAIR01=0: mih_wave_kernel scans shells 0 and 1 in separate passes

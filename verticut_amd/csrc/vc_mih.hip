@@ -550,6 +550,8 @@ __global__ void __launch_bounds__(256) mih_export_kernel(MihState st, const uint
   if (threadIdx.x == 0) cnt[q] = n;
 }
 
+__global__ void vc_add_u64_kernel(unsigned long long* p, unsigned long long v) { *p += v; }
+
 __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t n, uint32_t v) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -609,6 +611,9 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 #define MQ_MODE_APPROX 1u
 #define MQ_MODE_RADIUS 2u
 
+#define MQ_TAG (1ull << 63)             // k-NN candidate of the second shell of a paired pass
+static __host__ __device__ inline uint32_t mq_hist_bins(uint32_t W) { return (W * 64u + 1u + 7u) & ~7u; }
+
 struct QueryKernelParams {
   const uint64_t* cols;
   uint64_t stride, n;
@@ -647,6 +652,92 @@ __device__ __forceinline__ uint32_t mq_unrank(const uint32_t* sb, uint32_t j, ui
   return mask;
 }
 
+// smallest d with sum_{d' <= d} h[d'] >= k, 0xFFFFFFFF if the histogram holds fewer than k (one wave, LDS histogram)
+__device__ __forceinline__ uint32_t mw_hist_cut(const uint32_t* h, uint32_t nbins, uint32_t k) {
+  const uint32_t lane = vc_lane();
+  const uint32_t bpl = (nbins + VC_WAVE - 1) / VC_WAVE;
+  uint32_t mine = 0;
+  for (uint32_t i = 0; i < bpl; ++i) {
+    const uint32_t bin = lane * bpl + i;
+    if (bin < nbins) mine += h[bin];
+  }
+  uint32_t total;
+  uint32_t run = vc_wave_excl_scan(mine, total);
+  uint32_t cand = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < bpl; ++i) {
+    const uint32_t bin = lane * bpl + i;
+    if (bin < nbins) {
+      run += h[bin];
+      if (run >= k && cand == 0xFFFFFFFFu) cand = bin;
+    }
+  }
+  return vc_wave_min(cand);
+}
+
+// ---- k-NN candidate buffer of mih_query_kernel: s_buf[0 .. *s_ncand) unsorted, entries of the second shell of a paired
+// pass tagged with MQ_TAG.  Rare paths, deliberately NOT inlined (all threads of the block call them together).
+// Drop what the threshold has overtaken (and, when asked, the tagged entries), in place, 256 entries at a time.
+__device__ __noinline__ void mq_compact(uint64_t* s_buf, uint32_t* s_ncand, const uint64_t* s_thresh, uint32_t* s_wsum,
+                                        uint32_t buf_entries, bool drop_tagged) {
+  const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
+  __syncthreads();
+  const uint32_t fill = min(*s_ncand, buf_entries);
+  const uint64_t thr = *s_thresh;
+  uint32_t nf = 0;
+  for (uint32_t base = 0; base < fill; base += MQ_BLK) {
+    const uint32_t i = base + tid;
+    const uint64_t v = i < fill ? s_buf[i] : VC_PACK_INF;
+    const bool keep = i < fill && (v & ~MQ_TAG) < thr && !(drop_tagged && (v & MQ_TAG));
+    const uint64_t km = __ballot(keep);
+    if (lane == 0) s_wsum[wave] = (uint32_t)__popcll(km);
+    __syncthreads();                      // every thread has read its entry; the wave counts are visible
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < MQ_BLK / VC_WAVE; ++w) {
+      if (w < wave) before += s_wsum[w];
+      total += s_wsum[w];
+    }
+    if (keep) s_buf[nf + before + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = v;
+    nf += total;
+    __syncthreads();
+  }
+  if (tid == 0) *s_ncand = nf;
+  __syncthreads();
+}
+
+// Exact selection when ties overfill the buffer: sort (tagged entries behind the untagged ones) and keep the k best of
+// either kind -- a superset of the top-k of the first shell alone and of both shells together.
+__device__ __noinline__ void mq_select_exact(uint64_t* s_buf, uint32_t* s_ncand, uint64_t* s_thresh, uint32_t* s_tmp,
+                                             uint32_t buf_entries, uint32_t k) {
+  const uint32_t tid = threadIdx.x;
+  __syncthreads();
+  const uint32_t fill = min(*s_ncand, buf_entries);
+  uint32_t P = 2;
+  while (P < fill) P <<= 1;
+  for (uint32_t i = fill + tid; i < P; i += MQ_BLK) s_buf[i] = VC_PACK_INF;
+  vc_bitonic_lds(s_buf, P, MQ_BLK);
+  uint32_t mine = 0;
+  for (uint32_t i = tid; i < fill; i += MQ_BLK) mine += !(s_buf[i] & MQ_TAG);
+  if (tid == 0) *s_tmp = 0;
+  __syncthreads();
+  if (mine) atomicAdd(s_tmp, mine);
+  __syncthreads();
+  const uint32_t nU = *s_tmp;
+  const uint32_t keepU = min(nU, k), keepT = min(fill - nU, k);
+  for (uint32_t base = 0; base < keepT; base += MQ_BLK) {   // tagged survivors move up behind the untagged ones
+    const uint32_t i = base + tid;
+    const uint64_t v = i < keepT ? s_buf[nU + i] : 0;
+    __syncthreads();
+    if (i < keepT) s_buf[keepU + i] = v;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *s_ncand = keepU + keepT;
+    if (nU >= k && s_buf[k - 1] + 1 < *s_thresh) *s_thresh = s_buf[k - 1] + 1;   // exact bound for everything still to come
+  }
+  __syncthreads();
+}
+
 template <int W, uint32_t MQ_LO>
 __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kernel(const QueryKernelParams p) {
   constexpr uint32_t MQ_HI = 32u - MQ_LO;
@@ -661,9 +752,11 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   uint32_t* s_meta = s_pref + MQ_HMAX + 1;                   // [MQ_HMAX] table | substring distance << 8
   uint32_t* s_binom = s_meta + MQ_HMAX;                      // [33][MQ_BW]
   uint32_t* s_mask = s_binom + 33 * MQ_BW;                   // [m][MQ_NJ][MQ_GW] (32-bit substrings only)
+  const uint32_t HB = mq_hist_bins(W);
+  uint32_t* s_hist = s_mask + (p.sbits == 32 ? p.m * (MQ_LO_MAX + 1) * ((1u << MQ_LO_MAX) / 32u) : 0u);   // [2][HB] (k-NN modes)
   __shared__ VcTableView s_tv[64];
-  __shared__ uint32_t s_nh, s_ncand, s_seen, s_hits0, s_wsum[MQ_BLK / VC_WAVE];
-  __shared__ uint32_t s_segstart[28], s_segh[27], s_segmask[27], s_nseg;
+  __shared__ uint32_t s_nh, s_ncand, s_seen, s_seenB, s_hits0, s_hits0B, s_dk, s_wsum[MQ_BLK / VC_WAVE];
+  __shared__ uint32_t s_segstart[28], s_segh[27], s_segmask[27], s_segr[27], s_nseg;
   __shared__ uint64_t s_thresh;
 
   if (p.slot_count && blockIdx.x >= *p.slot_count) return;
@@ -689,11 +782,15 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   for (uint32_t i = tid; i < m * (sizeof(VcTableView) / 4); i += MQ_BLK) ((uint32_t*)s_tv)[i] = ((const uint32_t*)p.tables)[i];
   if (s == 32)
     for (uint32_t i = tid; i < m * MQ_NJ * MQ_GW; i += MQ_BLK) s_mask[i] = 0;
+  if (knn)
+    for (uint32_t i = tid; i < 2 * HB; i += MQ_BLK) s_hist[i] = 0;
   if (tid == 0) {
     s_nh = 0;
     s_ncand = 0;
     s_seen = 0;
+    s_seenB = 0;
     s_hits0 = 0;
+    s_hits0B = 0;
     s_thresh = knn ? VC_PACK_INF : vc_pack(p.radius + 1, 0);
   }
   __syncthreads();
@@ -717,7 +814,12 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     }
   }
 
-  uint32_t kk = 0;                 // committed top-k entries in s_buf[0..kk), ascending   (block-uniform)
+  // k-NN modes keep s_buf UNSORTED: s_buf[0 .. s_ncand) = the candidates that passed the running threshold, those of
+  // the second shell of a paired pass tagged with MQ_TAG.  The stop rule's k-th distance and the threshold come from a
+  // distance histogram in LDS (no sort per shell: the bitonic network after every shell was most of this kernel's
+  // instructions); the buffer is compacted when it fills and sorted once, when the query ends or is handed over.
+  uint32_t r_tag = 0xFFFFFFFFu;    // substring distance that marks the second shell of a paired pass (block-uniform)
+  uint32_t kk = 0;                 // radius mode: sorted results in s_buf[0..kk)           (block-uniform)
   bool spilled = false;            // radius mode: results went to the global ring unsorted (block-uniform)
   uint32_t ring_fill = 0;          // radius mode: entries already in the global ring       (block-uniform)
   unsigned long long sub = 0, loc = 0;   // get_stat counters of table 0 (block-uniform)
@@ -759,8 +861,23 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     __syncthreads();
   };
 
+  // ---- k-NN: rare paths of the candidate buffer live in functions of their own (mq_compact / mq_select_exact): inlined
+  // into every drain() they made the compiler outline drain() itself, closure and all
+  auto compact = [&](bool drop_tagged) { mq_compact(s_buf, &s_ncand, &s_thresh, s_wsum, p.buf_entries, drop_tagged); };
+  auto select_exact = [&]() { mq_select_exact(s_buf, &s_ncand, &s_thresh, &s_dk, p.buf_entries, p.k); };
+  // ---- k-NN: sorted top-k of what the evaluated shells have seen -> s_buf[0 .. return value)
+  auto finish_sort = [&]() -> uint32_t {
+    compact(true);
+    const uint32_t fill = s_ncand;
+    uint32_t P = 2;
+    while (P < fill) P <<= 1;
+    for (uint32_t i = fill + tid; i < P; i += MQ_BLK) s_buf[i] = VC_PACK_INF;
+    vc_bitonic_lds(s_buf, P, MQ_BLK);
+    return min(fill, p.k);
+  };
+
   // ---- drain the hit list: (rank -> offsets), prefix sum, balanced verify
-  auto drain = [&]() {
+  auto drain = [&]() __attribute__((always_inline)) {
     __syncthreads();
     const uint32_t H = min(s_nh, MQ_HMAX);
     if (s == 32) {
@@ -821,7 +938,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     w_hits += H;
     w_entries += total;
 
-    uint32_t seen_acc = 0;
+    uint32_t seen_acc = 0, seen_accB = 0;
     for (uint32_t e0 = 0; e0 < total; e0 += MQ_ROUND) {
       // room for one round of survivors behind what the buffer already holds.  The fill is read between two barriers:
       // the first ends the previous round's appends, the second keeps a fast wave's appends of THIS round from being
@@ -830,7 +947,12 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       const uint32_t fill = s_ncand;
       __syncthreads();
       if (kk + fill + MQ_ROUND > p.buf_entries) {
-        if (knn) merge(); else flush_ring();
+        if (knn) {
+          compact(false);
+          if (s_ncand + MQ_ROUND > p.buf_entries) select_exact();
+        } else {
+          flush_ring();
+        }
       }
       const uint64_t thresh = s_thresh;
       uint32_t local[MIH_EPT], meta[MIH_EPT];
@@ -892,17 +1014,24 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         }
         const uint64_t emask = __ballot(emit);
         if (emask == 0) continue;
-        seen_acc += (uint32_t)__popcll(emask);
+        const bool second = (meta[g] >> 8) == r_tag;     // candidate of the second shell of a paired pass
+        const uint64_t bmask = __ballot(emit && second);
+        seen_accB += (uint32_t)__popcll(bmask);
+        seen_acc += (uint32_t)__popcll(emask & ~bmask);
         const bool keep = emit && packed < thresh;
         const uint64_t kmask = __ballot(keep);
         if (kmask == 0) continue;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&s_ncand, (uint32_t)__popcll(kmask));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (keep) s_buf[kk + base + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull))] = packed;
+        if (keep) {
+          s_buf[kk + base + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull))] = second ? (packed | MQ_TAG) : packed;
+          if (knn) atomicAdd(&s_hist[(second ? HB : 0u) + (uint32_t)(packed >> 32)], 1u);
+        }
       }
     }
     if (lane == 0 && seen_acc) atomicAdd(&s_seen, seen_acc);
+    if (lane == 0 && seen_accB) atomicAdd(&s_seenB, seen_accB);
     __syncthreads();
     if (tid == 0) s_nh = 0;
     __syncthreads();
@@ -951,7 +1080,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           const uint32_t qk = qkey(t);
           gr[g] = (qk >> MQ_LO) ^ hi;
           qlo[g] = qk & ((1u << MQ_LO) - 1u);
-          meta0[g] = t | (s_segh[seg] << 8);
+          meta0[g] = t | (s_segh[seg] << 8) | (s_segr[seg] == r_tag ? 0x80000000u : 0u);
           mi[g] = t * MQ_NJ + s_segmask[seg];
           const uint4* gp = reinterpret_cast<const uint4*>(s_tv[t].bitmap + (uint64_t)gr[g] * MQ_GW);
 #pragma unroll
@@ -959,7 +1088,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         }
       }
       uint32_t w[MQ_G32][MQ_GW];
-      uint32_t cnt = 0, cnt0 = 0;
+      uint32_t cnt = 0, cnt0 = 0, cnt0b = 0;
 #pragma unroll
       for (uint32_t g = 0; g < MQ_G32; ++g) {
         const uint32_t* mk = s_mask + mi[g] * MQ_GW;
@@ -973,12 +1102,16 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           c += __popc(w[g][4 * cc + 0]) + __popc(w[g][4 * cc + 1]) + __popc(w[g][4 * cc + 2]) + __popc(w[g][4 * cc + 3]);
         }
         cnt += c;
-        if ((meta0[g] & 0xFFu) == 0 && tb_first == 0 && idx0 + g < per_table) cnt0 += c;
+        if ((meta0[g] & 0xFFu) == 0 && tb_first == 0 && idx0 + g < per_table) {
+          if (meta0[g] >> 31) cnt0b += c; else cnt0 += c;
+        }
       }
       if (p.flags & VC_FLAG_USE_BITMAP) {   // n_sub_reads_ of table 0 = its leaves whose bit is set (search_worker.cc:238-245)
-        uint32_t wt;
+        uint32_t wt, wtb;
         (void)vc_wave_excl_scan(cnt0, wt);
+        (void)vc_wave_excl_scan(cnt0b, wtb);
         if (lane == 0 && wt) atomicAdd(&s_hits0, wt);
+        if (lane == 0 && wtb) atomicAdd(&s_hits0B, wtb);
       }
       for (;;) {   // append this pass's hits; what does not fit waits for a drain
         if (!__syncthreads_or(cnt != 0)) break;
@@ -996,7 +1129,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
               w[g][i] &= w[g][i] - 1u;
               const uint32_t x = i * 32 + bb;
               s_key[pos] = (gr[g] << MQ_LO) | x;
-              s_meta[pos] = meta0[g] + (__popc(x ^ qlo[g]) << 8);
+              s_meta[pos] = (meta0[g] & 0xFFFFu) + (__popc(x ^ qlo[g]) << 8);
               ++pos;
               --cnt;
             }
@@ -1083,19 +1216,21 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   };
 
   // ---- segments of one pass over a 32-bit table: exact shell r (masks E_{r-h}) or the whole ball (masks B_{R-h})
-  auto plan32 = [&](uint32_t r, bool ball) {
+  auto plan32 = [&](uint32_t r_lo, uint32_t r_hi, bool ball) {   // (ball: one "shell" r_lo = r_hi with the cumulative masks)
     __syncthreads();
     if (tid == 0) {
       uint32_t ns = 0, start = 0;
-      for (uint32_t h = 0; h <= min(r, MQ_HI); ++h) {
-        const uint32_t j = r - h;
-        if (!ball && j > MQ_LO) continue;        // the low part holds at most MQ_LO flips
-        s_segstart[ns] = start;
-        s_segh[ns] = h;
-        s_segmask[ns] = min(j, MQ_LO);
-        start += s_binom[MQ_HI * MQ_BW + h];
-        ++ns;
-      }
+      for (uint32_t r = r_lo; r <= r_hi; ++r)
+        for (uint32_t h = 0; h <= min(r, MQ_HI); ++h) {
+          const uint32_t j = r - h;
+          if (!ball && j > MQ_LO) continue;        // the low part holds at most MQ_LO flips
+          s_segstart[ns] = start;
+          s_segh[ns] = h;
+          s_segmask[ns] = min(j, MQ_LO);
+          s_segr[ns] = r;
+          start += s_binom[MQ_HI * MQ_BW + h];
+          ++ns;
+        }
       s_segstart[ns] = start;
       s_nseg = ns;
     }
@@ -1104,13 +1239,21 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 
   const uint32_t S = s;            // loop bound radius <= n_local_bytes_ * 8 (search_worker.cc:170)
   if (knn && p.r_first) {          // resume: the state mih_wave_kernel handed over after shell r_first - 1
-    kk = min(p.st.count[slot], p.k);
-    for (uint32_t i = tid; i < kk; i += MQ_BLK) s_buf[i] = p.st.topk[(uint64_t)slot * p.k + i];
+    const uint32_t kin = min(p.st.count[slot], p.k);
+    for (uint32_t i = tid; i < kin; i += MQ_BLK) {
+      const uint64_t v = p.st.topk[(uint64_t)slot * p.k + i];
+      s_buf[i] = v;
+      atomicAdd(&s_hist[(uint32_t)(v >> 32)], 1u);
+    }
     sub = p.st.sub[slot];
     loc = p.st.loc[slot];
     if (tid == 0) {
+      s_ncand = kin;
       s_seen = (uint32_t)p.st.seen[slot];
-      s_thresh = p.st.thresh[slot];
+      // the hand-over threshold is the k-th best itself ("append iff better", the multi-block kernels' rule, which keep
+      // the committed top-k apart); here the committed entries live in the same buffer, so the bound is exclusive
+      const uint64_t th = p.st.thresh[slot];
+      s_thresh = th == VC_PACK_INF ? th : th + 1;
     }
     __syncthreads();
   }
@@ -1124,11 +1267,11 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     const uint32_t n_big = min(p.n_big, m);
     if (s == 32) {
       tb_first = 0; tb_count = n_big;
-      plan32(p.r_last, true);
+      plan32(p.r_last, p.r_last, true);
       scan32();
       if (n_big < m && p.small_shells) {
         tb_first = n_big; tb_count = m - n_big;
-        plan32(p.small_shells - 1, true);
+        plan32(p.small_shells - 1, p.small_shells - 1, true);
         scan32();
       }
     } else {
@@ -1160,64 +1303,97 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     return;
   }
 
-  for (uint32_t r = p.r_first; r <= p.r_last; ++r) {
+  for (uint32_t r = p.r_first; r <= p.r_last;) {
+    // shells 0 and 1 of 32-bit substrings share ONE pass (their 1 + 26 granules per table): the candidates of shell 1 are
+    // tagged and counted apart, the stop rule is evaluated for shell 0 alone first -- one scan / drain round less
+    const uint32_t r_hi = (s == 32 && r == 0 && p.pair01 && p.r_last >= 1) ? 1u : r;
+    r_tag = r_hi != r ? r_hi : 0xFFFFFFFFu;
     if (s == 32) {
-      plan32(r, false);
+      plan32(r, r_hi, false);
       scan32();
     } else {
       scan_direct(r);
     }
     if (s_nh) drain();
     __syncthreads();
-    if (s_ncand) merge();
-    // get_stat counters of table 0 (rank 0's, search_worker.cc:24-30): every leaf is a bitmap test when the bitmap
-    // is attached (:239) and a get only where the bit is set (:245); without it every leaf is a get
-    const unsigned long long leaves = c_binom[s][r];
-    w_probes += leaves * m;
-    if (p.flags & VC_FLAG_USE_BITMAP) {
-      loc += leaves;
-      sub += s_hits0;
-    } else {
-      sub += leaves;
-    }
-    __syncthreads();
-    if (tid == 0) s_hits0 = 0;
-    const uint64_t kth = kk == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
-    bool stop;
-    if (p.mode == MQ_MODE_APPROX)   // search_worker.cc:136-137: the heap of k*20 distinct candidates is full
-      stop = s_seen >= p.k * MIH_APPROX_FACTOR;
-    else                            // search_worker.cc:201-205: size == k && top.dist <= radius * 4 (radius already incremented)
-      stop = kk == p.k && (uint32_t)(kth >> 32) <= (r + 1) * p.stop_mult;
-    if (stop || r == S) {
-      put_work();
-      for (uint32_t i = tid; i < p.k; i += MQ_BLK) p.out[(uint64_t)slot * p.k + i] = i < kk ? s_buf[i] : VC_PACK_INF;
-      if (tid == 0) {
-        p.out_cnt[slot] = kk;
-        p.st.radius[slot] = r;     // find() returns radius - 1 = last shell searched
-        p.st.seen[slot] = s_seen;
-        p.st.sub[slot] = sub;
-        p.st.loc[slot] = loc;
+    for (uint32_t rr = r; rr <= r_hi; ++rr) {
+      if (rr != r) {                 // second shell of the pass: its candidates join the evaluated set
+        for (uint32_t i = tid; i < HB; i += MQ_BLK) {
+          s_hist[i] += s_hist[HB + i];
+          s_hist[HB + i] = 0;
+        }
+        const uint32_t fill = min(s_ncand, p.buf_entries);
+        for (uint32_t i = tid; i < fill; i += MQ_BLK) s_buf[i] &= ~MQ_TAG;
+        if (tid == 0) {
+          s_seen += s_seenB;
+          s_seenB = 0;
+          s_hits0 = s_hits0B;
+          s_hits0B = 0;
+        }
+        r_tag = 0xFFFFFFFFu;
+        __syncthreads();
       }
-      return;
+      // get_stat counters of table 0 (rank 0's, search_worker.cc:24-30): every leaf is a bitmap test when the bitmap
+      // is attached (:239) and a get only where the bit is set (:245); without it every leaf is a get
+      const unsigned long long leaves = c_binom[s][rr];
+      w_probes += leaves * m;
+      if (p.flags & VC_FLAG_USE_BITMAP) {
+        loc += leaves;
+        sub += s_hits0;
+      } else {
+        sub += leaves;
+      }
+      const uint32_t seen = s_seen;
+      __syncthreads();
+      if (tid == 0) s_hits0 = 0;
+      if (wave == 0) {               // k-th distance among the candidates of the shells evaluated so far
+        const uint32_t cut = seen >= p.k ? mw_hist_cut(s_hist, W * 64u + 1u, p.k) : 0xFFFFFFFFu;
+        if (lane == 0) s_dk = cut;
+      }
+      __syncthreads();
+      const uint32_t dk = s_dk;
+      bool stop;
+      if (p.mode == MQ_MODE_APPROX)   // search_worker.cc:136-137: the heap of k*20 distinct candidates is full
+        stop = seen >= p.k * MIH_APPROX_FACTOR;
+      else                            // search_worker.cc:201-205: size == k && top.dist <= radius * 4 (radius already incremented)
+        stop = dk != 0xFFFFFFFFu && dk <= (rr + 1) * p.stop_mult;
+      if (stop || rr == S) {
+        const uint32_t kout = finish_sort();
+        put_work();
+        for (uint32_t i = tid; i < p.k; i += MQ_BLK) p.out[(uint64_t)slot * p.k + i] = i < kout ? s_buf[i] : VC_PACK_INF;
+        if (tid == 0) {
+          p.out_cnt[slot] = kout;
+          p.st.radius[slot] = rr;     // find() returns radius - 1 = last shell searched
+          p.st.seen[slot] = seen;
+          p.st.sub[slot] = sub;
+          p.st.loc[slot] = loc;
+        }
+        return;
+      }
+      if (tid == 0 && dk != 0xFFFFFFFFu) {   // everything farther than the k-th distance is out for good
+        const uint64_t bnd = ((uint64_t)dk + 1) << 32;
+        if (bnd < s_thresh) s_thresh = bnd;
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    r = r_hi + 1;
   }
   // not finished: hand the query to the multi-block shells (state exactly as mih_commit_kernel leaves it)
+  const uint32_t kout = finish_sort();
   put_work();
-  for (uint32_t i = tid; i < kk; i += MQ_BLK) p.st.topk[(uint64_t)slot * p.k + i] = s_buf[i];   // mih_seed_ring_kernel moves it into the ring
+  for (uint32_t i = tid; i < kout; i += MQ_BLK) p.st.topk[(uint64_t)slot * p.k + i] = s_buf[i];   // mih_seed_ring_kernel moves it into the ring
   if (tid == 0) {
-    p.st.count[slot] = kk;
-    p.st.prev[slot] = kk;
-    p.st.thresh[slot] = kk == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
+    p.st.count[slot] = kout;
+    p.st.prev[slot] = kout;
+    p.st.thresh[slot] = kout == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
     p.st.seen[slot] = s_seen;
     p.st.sub[slot] = sub;
     p.st.loc[slot] = loc;
     p.st.radius[slot] = 0;
-    p.st.topn[slot] = kk;
+    p.st.topn[slot] = kout;
     p.heavy_list[atomicAdd(p.heavy_ctr, 1u)] = slot;
   }
 }
-
 
 // =============================================================================================================
 // mih_wave_kernel -- ONE WAVE runs a query's radius loop (32-bit substrings, k-NN modes, shells 0..r_last).
@@ -1250,7 +1426,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 #define MW_WAVES 3                      // waves per SIMD the kernel is compiled for (3: <= 168 VGPRs, no spills at W <= 2)
 #endif
 #define MW_ROUND (VC_WAVE * MW_EPT)
-#define MW_TAG (1ull << 63)             // candidate of the second shell of a paired pass
+#define MW_TAG MQ_TAG
 #define MW_MAXSEG 20u
 
 __device__ __forceinline__ void mw_sync() {   // orders one wave's LDS traffic for the compiler (the hardware keeps it in order)
@@ -1259,32 +1435,9 @@ __device__ __forceinline__ void mw_sync() {   // orders one wave's LDS traffic f
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// smallest d with sum_{d' <= d} h[d'] >= k, 0xFFFFFFFF if the histogram holds fewer than k (one wave, LDS histogram)
-__device__ __forceinline__ uint32_t mw_hist_cut(const uint32_t* h, uint32_t nbins, uint32_t k) {
-  const uint32_t lane = vc_lane();
-  const uint32_t bpl = (nbins + VC_WAVE - 1) / VC_WAVE;
-  uint32_t mine = 0;
-  for (uint32_t i = 0; i < bpl; ++i) {
-    const uint32_t bin = lane * bpl + i;
-    if (bin < nbins) mine += h[bin];
-  }
-  uint32_t total;
-  uint32_t run = vc_wave_excl_scan(mine, total);
-  uint32_t cand = 0xFFFFFFFFu;
-  for (uint32_t i = 0; i < bpl; ++i) {
-    const uint32_t bin = lane * bpl + i;
-    if (bin < nbins) {
-      run += h[bin];
-      if (run >= k && cand == 0xFFFFFFFFu) cand = bin;
-    }
-  }
-  return vc_wave_min(cand);
-}
-
-static __host__ __device__ inline uint32_t mw_hist_bins(uint32_t W) { return (W * 64u + 1u + 7u) & ~7u; }
 // per-wave LDS of mih_wave_kernel: candidate buffer | hit list (key, prefix, meta) | 2 distance histograms | masks | segment plan
 static __host__ __device__ inline size_t mw_wave_bytes(uint32_t cb, uint32_t W, uint32_t m) {
-  const size_t b = (size_t)cb * 8 + (size_t)(3 * MW_HM + 1) * 4 + (size_t)2 * mw_hist_bins(W) * 4 +
+  const size_t b = (size_t)cb * 8 + (size_t)(3 * MW_HM + 1) * 4 + (size_t)2 * mq_hist_bins(W) * 4 +
                    (size_t)m * (MQ_LO_KNN + 1) * ((1u << MQ_LO_KNN) / 32u) * 4 + (size_t)(4 * MW_MAXSEG + 4) * 4;
   return (b + 15) & ~(size_t)15;
 }
@@ -1298,7 +1451,7 @@ __global__ void __launch_bounds__(256, MW_WAVES) mih_wave_kernel(const QueryKern
   static_assert(GW == 4, "one 16-byte load per granule");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
-  const uint32_t m = p.m, CB = p.buf_entries, HB = mw_hist_bins(W);
+  const uint32_t m = p.m, CB = p.buf_entries, HB = mq_hist_bins(W);
   VcTableView* s_tv = (VcTableView*)smem;
   uint32_t* s_binom = (uint32_t*)(s_tv + m);
   unsigned char* wb = smem + mw_shared_bytes(m) + (size_t)wave * mw_wave_bytes(CB, W, m);
@@ -1736,6 +1889,295 @@ __global__ void __launch_bounds__(256, MW_WAVES) mih_wave_kernel(const QueryKern
 }
 
 
+// =============================================================================================================
+// mih_bucket_stream_kernel -- fixed-radius search over <= 16-bit substrings (BASELINE configs[1], m = 4 x 16 bit):
+// the buckets hold ~N / 2^s entries each (1 526 at 1e8 codes), so a query is not a chain of probes but a STREAM of
+// bucket entries -- 188 buckets, 287 K entries per query at R = 8 -- and the work is HBM-bound byte work:
+//   * a block takes one query (or one of `split` interleaved parts of its probe list), its threads look the probes up
+//     once (key by combination unranking, direct offsets: search_worker.cc:230-246) into an LDS list of (offset, length);
+//   * every WAVE then streams whole buckets from the table's bucket-order code copy (VcTableView::bcodes: contiguous,
+//     512 bytes per wave-instruction, MS_U instructions in flight per lane) and tests the FULL distance only:
+//     xor + popcount + compare per entry, no id load, no LDS search, no workgroup barrier in the loop;
+//   * the rare entry within the radius pays for the owner rule (per-substring distances) and its id, and is appended to
+//     the query's result ring with one atomic per wave.
+// Algorithmic bytes: probes x 8 (two offsets) + entries x B/8; measured by the kernel's own counters (vc_timing.mih_*).
+// =============================================================================================================
+#define MS_U 8u                          // bucket entries per lane in flight
+#define MS_MAXP 2048u                    // probes of one query (all tables, all shells) held in LDS
+
+struct StreamParams {
+  const uint64_t* queries;               // [nq][W]
+  const VcTableView* tables;
+  uint64_t* ring;                        // [nq][cap]
+  uint32_t* count;                       // [nq]
+  unsigned long long* totals;            // probes | non-empty buckets | entries | -
+  uint64_t n;                            // entries per table (stride of the bucket-order copies)
+  uint32_t m, sbits, id_base, flags, cap, radius;
+  uint32_t rsub, n_big, small_shells;    // shells 0..rsub for tables 0..n_big-1, shells 0..small_shells-1 for the others
+  uint32_t nprobes, split;
+};
+
+template <int W>
+__global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamParams p) {
+  __shared__ uint32_t s_off[MS_MAXP], s_len[MS_MAXP], s_meta[MS_MAXP];
+  __shared__ unsigned long long s_tot[2];
+  const uint32_t slot = blockIdx.x / p.split, part = blockIdx.x % p.split;
+  const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
+  const uint32_t s = p.sbits, m = p.m, smask = (1u << s) - 1u;
+  uint64_t qw[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) qw[j] = p.queries[(uint64_t)slot * W + j];
+  auto qkey = [&](uint32_t t) {
+    const uint32_t bp = t * s;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if ((uint32_t)j == (bp >> 6)) v = (uint32_t)(qw[j] >> (bp & 63)) & smask;
+    return v;
+  };
+  if (tid < 2) s_tot[tid] = 0;
+  __syncthreads();
+  // ---- this block's probes: j = part, part + split, ...  ->  (shell r, table t, index in the shell) -> bucket
+  uint32_t nloc = 0;
+  unsigned long long hits = 0, entries = 0;
+  for (uint32_t li = tid;; li += blockDim.x) {
+    uint32_t j = part + li * p.split;
+    if (j >= p.nprobes) break;
+    uint32_t r = 0, t = 0;
+    for (;; ++r) {
+      const uint32_t per = c_binom[s][r], cnt = (r < p.small_shells ? m : p.n_big) * per;
+      if (j < cnt) {
+        t = j / per;
+        j -= t * per;
+        break;
+      }
+      j -= cnt;
+    }
+    const uint32_t mask = r ? vc_unrank(j, r, s) : 0u;
+    // binaryToInt's sign-extended keys (Pilaf/image_tools.h:13): a probe that flips the top bit matches nothing
+    const bool dead = (p.flags & VC_FLAG_REF_SIGNEXT_KEYS) && ((mask >> (s - 1)) & 1u);
+    uint32_t off = 0, len = 0;
+    if (!dead) {
+      const uint32_t key = qkey(t) ^ mask;
+      off = p.tables[t].offsets[key];
+      len = p.tables[t].offsets[key + 1] - off;
+    }
+    s_off[li] = off;
+    s_len[li] = len;
+    s_meta[li] = t | (r << 8);
+    hits += len != 0;
+    entries += len;
+  }
+  nloc = (p.nprobes > part) ? (p.nprobes - part + p.split - 1) / p.split : 0;
+  if (hits) atomicAdd(&s_tot[0], hits);
+  if (entries) atomicAdd(&s_tot[1], entries);
+  __syncthreads();
+  if (tid == 0 && p.totals) {
+    atomicAdd(&p.totals[1], s_tot[0]);
+    atomicAdd(&p.totals[2], s_tot[1]);
+    if (part == 0) atomicAdd(&p.totals[0], (unsigned long long)p.nprobes);
+  }
+  // ---- every wave streams whole buckets
+  uint64_t* const ring = p.ring + (uint64_t)slot * p.cap;
+  for (uint32_t b = wave; b < nloc; b += blockDim.x / VC_WAVE) {
+    const uint32_t off = s_off[b], len = s_len[b], t = s_meta[b] & 0xFFu, dt = s_meta[b] >> 8;
+    if (len == 0) continue;
+    const uint64_t* bc = p.tables[t].bcodes;
+    for (uint32_t e0 = 0; e0 < len; e0 += VC_WAVE * MS_U) {
+      uint64_t x[MS_U][W];
+#pragma unroll
+      for (uint32_t u = 0; u < MS_U; ++u) {
+        const uint32_t e = e0 + u * VC_WAVE + lane;
+        const uint32_t pos = off + (e < len ? e : 0u);   // clamp: entry 0 exists
+#pragma unroll
+        for (int j = 0; j < W; ++j) x[u][j] = __builtin_nontemporal_load(bc + (uint64_t)j * p.n + pos);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < MS_U; ++u) {
+        const uint32_t e = e0 + u * VC_WAVE + lane;
+        uint32_t dist = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) dist += (uint32_t)__popcll(x[u][j] ^ qw[j]);
+        bool hit = e < len && dist <= p.radius;
+        if (__ballot(hit) == 0) continue;
+        if (hit) {   // owner rule (mih_probe_kernel): reported by the first table holding the minimum substring distance
+          for (uint32_t tt = 0; tt < m; ++tt) {
+            const uint32_t bp = tt * s;
+            uint32_t field = 0;
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+              if ((uint32_t)j == (bp >> 6)) field = (uint32_t)((x[u][j] ^ qw[j]) >> (bp & 63)) & smask;
+            const uint32_t d = __popc(field);
+            bool reach = true;
+            if (p.flags & VC_FLAG_REF_SIGNEXT_KEYS) reach = ((field >> (s - 1)) & 1u) == 0;
+            if (tt != t && reach && (d < dt || (d == dt && tt < t))) hit = false;
+          }
+        }
+        const uint64_t km = __ballot(hit);
+        if (km == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&p.count[slot], (uint32_t)__popcll(km));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (hit) {
+          const uint32_t at = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+          if (at < p.cap) ring[at] = vc_pack(dist, p.id_base + p.tables[t].ids[off + e]);
+        }
+      }
+    }
+  }
+}
+
+
+// =============================================================================================================
+// Cost-model switch of the exact k-NN loop: kernels (see VcMihScanFallback, vc_mih.hpp).
+//
+// The radius loop of search_worker.cc:159-218 stops after shell r iff k items have been seen and the k-th best distance
+// K_r among them is <= mult * (r + 1) (:201-205).  An item is SEEN in shell r iff its minimum substring distance is
+// <= r; every item with full distance < m (r + 1) has been seen by then (pigeonhole).  With D = the k-th smallest
+// distance of the whole database (what the scan finds) and mult = min(m, 4):
+//   mult < m:  the loop stops at the first r with mult (r + 1) >= D -- all items at or below D are seen by then, so the
+//              result is the scan's top-k and radius = ceil(D / mult) - 1 (0 for D = 0);
+//   mult = m:  r0 = D / m.  If m does not divide D (or D = 0) the loop stops at r0 with the scan's top-k.  If D = m r0 > 0
+//              it may stop one shell EARLY: after shell r0 - 1 every item below D has been seen, and of the items AT D all
+//              but those whose m substrings sit at exactly r0 each; if these make up k, radius = r0 - 1 and the result is
+//              the k best among them, else radius = r0 and the result is the scan's top-k.
+// The scan's candidate ring holds every item at or below D (the filter accepts d <= tau and tau never drops below D), so
+// the ties are examined from the ring.  n_sub_reads = every leaf of shells 0..radius (no bitmap attached on this path).
+// =============================================================================================================
+__global__ void __launch_bounds__(256) mih_gather_queries_kernel(const uint64_t* __restrict__ q, const uint32_t* __restrict__ list,
+                                                                 uint32_t n, uint32_t W, uint64_t* __restrict__ out) {
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n * W; e += gridDim.x * blockDim.x)
+    out[e] = q[(uint64_t)list[e / W] * W + e % W];
+}
+
+#define MR_TIES 8192u
+__global__ void __launch_bounds__(256) mih_replay_kernel(const VcMihReplayArgs a) {
+  __shared__ uint64_t s_tie[MR_TIES];
+  __shared__ uint32_t s_ntie, s_below;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t slot = a.list[q];
+  const uint32_t raw = a.lin_count[(size_t)q * a.lin_qs], nres = a.rows_cnt[q];
+  const uint64_t* row = a.rows + (uint64_t)q * a.k;
+  const uint32_t S = a.sbits, m = a.m;
+  auto unresolved = [&]() {
+    if (tid == 0) {
+      a.unresolved[atomicAdd(a.n_unresolved, 1u)] = slot;
+      a.resolved_flag[q] = 0;
+    }
+  };
+  if (raw > a.lin_cap || nres == 0xFFFFFFFFu) { unresolved(); return; }
+  uint32_t r_stop = 0, B = 0;
+  bool early = false;
+  if (tid == 0) { s_ntie = 0; s_below = 0; }
+  __syncthreads();
+  if (nres < a.k) {
+    r_stop = S;                                    // fewer than k items: the loop runs to its last shell (search_worker.cc:170)
+  } else {
+    const uint32_t D = (uint32_t)(row[a.k - 1] >> 32);
+    if (a.stop_mult < m) {
+      r_stop = D == 0 ? 0u : (D + a.stop_mult - 1) / a.stop_mult - 1;
+    } else {
+      const uint32_t r0 = D / m;
+      r_stop = r0;
+      if (D != 0 && D % m == 0) {
+        uint32_t mine = 0;
+        for (uint32_t i = tid; i < a.k; i += blockDim.x) mine += (uint32_t)(row[i] >> 32) < D;
+        if (mine) atomicAdd(&s_below, mine);
+        // ties at D that shell r0 - 1 has seen: some substring below r0 (the substrings sum to m r0, so not all equal r0)
+        const uint64_t* ring = a.lin_ring + (uint64_t)q * a.lin_cap;
+        const uint32_t smask = S == 32 ? 0xFFFFFFFFu : ((1u << S) - 1u);
+        for (uint32_t e = tid; e < raw; e += blockDim.x) {
+          const uint64_t v = ring[e];
+          if ((uint32_t)(v >> 32) != D) continue;
+          const uint32_t local = (uint32_t)v - a.id_base;
+          bool all_eq = true;
+          for (uint32_t t = 0; t < m; ++t) {
+            const uint32_t bp = t * S;
+            const uint64_t x = a.cols[(uint64_t)(bp >> 6) * a.stride + local] ^ a.queries[(uint64_t)q * a.W + (bp >> 6)];
+            all_eq = all_eq && (uint32_t)__popc((uint32_t)(x >> (bp & 63)) & smask) == r0;
+          }
+          if (!all_eq) {
+            const uint32_t at = atomicAdd(&s_ntie, 1u);
+            if (at < MR_TIES) s_tie[at] = v;
+          }
+        }
+        __syncthreads();
+        B = s_below;
+        const uint32_t nt = s_ntie;
+        if (nt > MR_TIES) { unresolved(); return; }   // (block-uniform)
+        if (B + nt >= a.k) {
+          early = true;
+          r_stop = r0 - 1;
+          uint32_t P = 2;
+          while (P < nt) P <<= 1;
+          for (uint32_t i = nt + tid; i < P; i += blockDim.x) s_tie[i] = VC_PACK_INF;
+          vc_bitonic_lds(s_tie, P, blockDim.x);
+        }
+      }
+    }
+  }
+  uint64_t* out = a.tgt.ring + (uint64_t)slot * a.tgt.cap;
+  for (uint32_t i = tid; i < nres; i += blockDim.x) out[i] = (early && i >= B) ? s_tie[i - B] : row[i];
+  if (tid == 0) {
+    a.tgt.count[slot] = nres;
+    a.tgt.radius[slot] = r_stop;
+    unsigned long long leaves = 0;
+    for (uint32_t r = 0; r <= r_stop; ++r) leaves += c_binom[S][r];
+    a.tgt.sub[slot] = leaves;
+    a.tgt.loc[slot] = 0;
+    a.tgt.seen[slot] = 0;
+    a.resolved_flag[q] = 1;
+  }
+}
+
+// distinct items the radius loop would have verified up to shell radius[slot]: minimum substring distance <= radius.
+// Up to 8 queries per pass over the database; counters in registers, one atomic per block and query at the end.
+#define MC_Q 8
+template <int W>
+__global__ void __launch_bounds__(256) mih_minsub_count_kernel(const uint64_t* __restrict__ cols, uint64_t stride, uint64_t n, uint32_t m,
+                                                               uint32_t sbits, const uint64_t* __restrict__ queries,
+                                                               const uint32_t* __restrict__ list, const uint32_t* __restrict__ flag,
+                                                               uint32_t nq, const uint32_t* __restrict__ radius,
+                                                               unsigned long long* __restrict__ seen) {
+  __shared__ uint64_t sq[MC_Q][W];
+  __shared__ uint32_t srad[MC_Q];
+  for (uint32_t i = threadIdx.x; i < nq * W; i += blockDim.x) sq[i / W][i % W] = queries[i];
+  for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) srad[i] = flag[i] ? radius[list[i]] : 0xFFFFFFFFu;   // unsettled: counts nothing useful
+  __syncthreads();
+  const uint32_t smask = sbits == 32 ? 0xFFFFFFFFu : ((1u << sbits) - 1u);
+  unsigned long long cnt[MC_Q];
+#pragma unroll
+  for (int q = 0; q < MC_Q; ++q) cnt[q] = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t c[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) c[j] = __builtin_nontemporal_load(cols + (uint64_t)j * stride + i);
+#pragma unroll
+    for (int q = 0; q < MC_Q; ++q) {
+      if ((uint32_t)q >= nq) break;
+      uint32_t ms = 0xFFFFFFFFu;
+      for (uint32_t t = 0; t < m; ++t) {
+        const uint32_t bp = t * sbits;
+        uint32_t field = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          if ((uint32_t)j == (bp >> 6)) field = (uint32_t)((c[j] ^ sq[q][j]) >> (bp & 63)) & smask;
+        ms = min(ms, (uint32_t)__popc(field));
+      }
+      cnt[q] += ms <= srad[q] && srad[q] != 0xFFFFFFFFu;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MC_Q; ++q) {
+    if ((uint32_t)q >= nq) break;
+    unsigned long long v = cnt[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, VC_WAVE);
+    if (vc_lane() == 0 && v && flag[q]) atomicAdd(&seen[list[q]], v);
+  }
+}
+
+
 // sum the per-query work counters of one mih_query_kernel launch into the index-wide totals (vc_get_timing)
 __global__ void __launch_bounds__(256) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
                                                               unsigned long long* __restrict__ totals, const uint32_t* __restrict__ list,
@@ -1842,6 +2284,36 @@ __global__ void __launch_bounds__(256) vc_compact_segments_kernel(const uint64_t
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+hipError_t vc_launch_gather_queries(const uint64_t* d_q, const uint32_t* d_list, uint32_t n, uint32_t W, uint64_t* d_out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(mih_gather_queries_kernel, dim3((n * W + 255) / 256), dim3(256), 0, s, d_q, d_list, n, W, d_out);
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_mih_replay(const VcMihReplayArgs& a, hipStream_t s) {
+  if (a.gq == 0) return hipSuccess;
+  hipLaunchKernelGGL(mih_replay_kernel, dim3(a.gq), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_minsub_count(const uint64_t* cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t m, uint32_t sbits,
+                                  const uint64_t* d_queries, const uint32_t* d_list, const uint32_t* d_flag, uint32_t nq,
+                                  const uint32_t* d_radius, unsigned long long* d_seen, uint32_t n_cu, hipStream_t s) {
+  for (uint32_t q0 = 0; q0 < nq; q0 += MC_Q) {
+    const uint32_t qt = std::min<uint32_t>(MC_Q, nq - q0);
+    const dim3 grid((uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)n_cu * 8));
+#define MC_CASE(W_) case W_: hipLaunchKernelGGL(mih_minsub_count_kernel<W_>, grid, dim3(256), 0, s, cols, stride, n, m, sbits, d_queries + (size_t)q0 * W, d_list + q0, d_flag + q0, qt, d_radius, d_seen); break;
+    switch (W) {
+      MC_CASE(1) MC_CASE(2) MC_CASE(4) MC_CASE(8)
+      default: return hipErrorInvalidValue;
+    }
+#undef MC_CASE
+    hipError_t r = hipGetLastError();
+    if (r != hipSuccess) return r;
+  }
+  return hipSuccess;
+}
+
 struct VcMihIndex {
   uint32_t W = 0, m = 0, sbits = 0, id_base = 0, flags = 0, n_cu = 0, cap = 0;
   uint64_t n = 0;
@@ -1873,7 +2345,7 @@ struct VcMihIndex {
     }                                                                                                    \
   } while (0)
 
-static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits);
+static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits, uint32_t W);
 static uint32_t grid_for(uint64_t n, uint32_t n_cu) { return (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)n_cu * 16); }
 
 static size_t device_lds_per_block() {
@@ -2466,12 +2938,14 @@ static hipError_t launch_probe(const ProbeParams& p, uint32_t W, uint32_t n_list
   return hipGetLastError();
 }
 
-static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits) {
-  return (size_t)buf_entries * 8 + (size_t)(3 * MQ_HMAX + 1) * 4 + (size_t)33 * MQ_BW * 4 + (sbits == 32 ? (size_t)m * (MQ_LO_MAX + 1) * ((1u << MQ_LO_MAX) / 32u) * 4 : 0) + 16;   // masks sized for the widest granule
+static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits, uint32_t W = VC_MAX_W) {
+  return (size_t)buf_entries * 8 + (size_t)(3 * MQ_HMAX + 1) * 4 + (size_t)33 * MQ_BW * 4 +
+         (sbits == 32 ? (size_t)m * (MQ_LO_MAX + 1) * ((1u << MQ_LO_MAX) / 32u) * 4 : 0) +   // masks sized for the widest granule
+         (size_t)2 * mq_hist_bins(W) * 4 + 16;                                                  // k-NN distance histograms
 }
 
 static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s) {
-  const size_t lds = query_kernel_lds(p.buf_entries, p.m, p.sbits);
+  const size_t lds = query_kernel_lds(p.buf_entries, p.m, p.sbits, W);
 #define MQ_LAUNCH(W_)                                                                                           \
   case W_:                                                                                                      \
     if (p.mode == MQ_MODE_RADIUS) hipLaunchKernelGGL((mih_query_kernel<W_, MQ_LO_RADIUS>), dim3(nq), dim3(MQ_BLK), lds, s, p); \
@@ -2529,6 +3003,40 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p,
   return hipGetLastError();
 }
 
+// launch + measurement of mih_bucket_stream_kernel (same records as the query kernels: vc_timing.mih_*)
+static hipError_t timed_stream_launch(VcMihIndex* ix, StreamParams sp, uint32_t W, uint32_t nq, hipStream_t s) {
+  if (!ix->d_totals) {
+    hipError_t r = hipMalloc((void**)&ix->d_totals, 32);
+    if (r == hipSuccess) r = hipMemsetAsync(ix->d_totals, 0, 32, s);
+    if (r != hipSuccess) return r;
+  }
+  sp.totals = ix->d_totals;
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (ix->ev_used < 4096) {
+    if (ix->ev_used == ix->ev_pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) == hipSuccess) {
+        if (hipEventCreate(&b) == hipSuccess) ix->ev_pool.emplace_back(a, b); else (void)hipEventDestroy(a);
+      }
+    }
+    if (ix->ev_used < ix->ev_pool.size()) ev = &ix->ev_pool[ix->ev_used++];
+  }
+  if (ev) (void)hipEventRecord(ev->first, s);
+  const dim3 grid(nq * sp.split);
+  switch (W) {
+    case 1: hipLaunchKernelGGL(mih_bucket_stream_kernel<1>, grid, dim3(256), 0, s, sp); break;
+    case 2: hipLaunchKernelGGL(mih_bucket_stream_kernel<2>, grid, dim3(256), 0, s, sp); break;
+    case 4: hipLaunchKernelGGL(mih_bucket_stream_kernel<4>, grid, dim3(256), 0, s, sp); break;
+    case 8: hipLaunchKernelGGL(mih_bucket_stream_kernel<8>, grid, dim3(256), 0, s, sp); break;
+    default: return hipErrorInvalidValue;
+  }
+  hipError_t r = hipGetLastError();
+  if (ev) (void)hipEventRecord(ev->second, s);
+  if (r != hipSuccess) return r;
+  hipLaunchKernelGGL(vc_add_u64_kernel, dim3(1), dim3(1), 0, s, ix->d_totals + 3, (unsigned long long)nq);
+  return hipGetLastError();
+}
+
 void vc_mih_timing(VcMihIndex* ix, float* ms, uint32_t* launches, uint64_t totals[4], hipStream_t s) {
   *ms = 0;
   *launches = 0;
@@ -2579,7 +3087,7 @@ static uint32_t inblock_last_shell(uint32_t S, uint32_t m, uint64_t budget, uint
 
 int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint64_t n, const uint64_t* d_q, uint32_t nq,
                   uint32_t k, bool approximate, uint64_t* d_out, uint32_t* d_cnt, vc_query_stats* stats, hipStream_t s,
-                  std::string* err) {
+                  std::string* err, const VcMihScanFallback* fb) {
   if (n != ix->n) {
     if (err) *err = "index is stale: codes were added after vc_build_index()";
     return VC_ERR_STATE;
@@ -2596,12 +3104,12 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
 
   // Shells 0..r_last run inside ONE launch, one block per query (mih_query_kernel); the host reads ONE counter per
   // tile (how many queries are not finished) and only those continue shell by shell through the multi-block kernels.
-  uint32_t buf_entries = 1024;
-  while (buf_entries < k + MQ_ROUND) buf_entries <<= 1;
+  uint32_t buf_entries = 1024;     // candidates of one block: up to k of either shell of a paired pass + one round of survivors
+  while (buf_entries < 2 * k + MQ_ROUND) buf_entries <<= 1;
   // the query kernel's LDS request (top-k + candidate buffer, hit lists, binomials, masks) must fit a workgroup of this
   // device (k = 3073..7168 asks for ~82 KB); otherwise every shell runs through the multi-block kernels
   const bool inblock = ix->knobs.mih_host_loop == 0 && buf_entries <= 8192 && ix->m <= 64 &&
-                       query_kernel_lds(buf_entries, ix->m, S) <= ix->lds_per_block;
+                       query_kernel_lds(buf_entries, ix->m, S, ix->W) <= ix->lds_per_block;
   if ((rc = ensure_tile(ix, k, cap, !inblock, &st, err))) return rc;
   uint32_t* lists[4] = {ix->d_lists, ix->d_lists + MIH_QTILE, ix->d_lists + 2 * MIH_QTILE, ix->d_lists + 3 * MIH_QTILE};
   uint32_t* d_ctr = ix->d_lists + 4 * MIH_QTILE;
@@ -2614,6 +3122,9 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   if (ix->knobs.mih_budget) knn_budget = ix->knobs.mih_budget;   // dev knob VC_MIH_BUDGET
   const uint32_t r_last = inblock_last_shell(S, ix->m, knn_budget, S, avg_bucket);
   const bool trace = ix->knobs.mih_trace;   // VC_MIH_TRACE: per-shell wall times on stderr
+  // the scan switch reproduces the radius loop only where that loop is exact and its counters have a closed form
+  const bool switch_ok = !approximate && ix->knobs.mih_switch != 0 && !(ix->flags & (VC_FLAG_USE_BITMAP | VC_FLAG_REF_SIGNEXT_KEYS)) &&
+                         stop_mult == std::min(ix->m, 4u) && n >= 1;
   // mih_wave_kernel: 32-bit substrings, k small enough for a per-wave candidate buffer of 2k + one round of survivors
   uint32_t wave_cb = 512;
   while (wave_cb < 2 * k + MW_ROUND) wave_cb <<= 1;
@@ -2634,7 +3145,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       qp.st = st; qp.m = ix->m; qp.sbits = S; qp.id_base = ix->id_base; qp.flags = ix->flags; qp.cap = cap; qp.k = k;
       qp.mode = approximate ? MQ_MODE_APPROX : MQ_MODE_EXACT; qp.stop_mult = stop_mult; qp.r_last = r_last;
       qp.buf_entries = buf_entries; qp.heavy_list = cur; qp.heavy_ctr = d_ctr + 2;
-      qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0;
+      qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0; qp.pair01 = ix->knobs.mih_pair01 ? 1u : 0u;
       const auto t_q = std::chrono::steady_clock::now();
       MIH_CHECK(hipMemsetAsync(d_ctr, 0, 16, s));
       if (wave_ok) {
@@ -2678,7 +3189,32 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, cur, (uint64_t)VC_PACK_INF);
       MIH_CHECK(hipGetLastError());
     }
+    bool switched = false;
     for (uint32_t r = r_start; r <= S && n_cur; ++r) {       // search_worker.cc:170: radius <= n_local_bytes_*8
+      // Cost model: this shell alone is m * C(S, r) bucket probes per active query (the multi-block kernels sustain ~4e10
+      // probes/s plus ~40 us of launches and a host round trip per shell); a verify pass streams the shard once per 8
+      // queries at ~6 TB/s (x 2.5 when the statistics pass is wanted).  Beyond the break-even the remaining queries are
+      // answered by the scan with the stop rule replayed -- same rows, same statistics (see mih_replay_kernel).
+      if (fb && fb->fn && switch_ok && !switched) {
+        const double est_mih = (double)n_cur * ix->m * binom_host(S, r) / 4e10 + 40e-6;
+        const double est_scan = (double)((n_cur + 7) / 8) * ((double)n * ix->W * 8 / 6e12 + 40e-6) * (stats ? 2.5 : 1.0);
+        if (est_mih > est_scan || ix->knobs.mih_switch == 2) {
+          VcMihScanTarget tgt{st.ring, cap, st.count, st.radius, st.seen, st.sub, st.loc};
+          MIH_CHECK(hipMemsetAsync(d_ctr, 0, 8, s));
+          rc = fb->fn(fb->ctx, d_q + (size_t)q0 * ix->W, cur, n_cur, k, stop_mult, tgt, stats != nullptr, nxt, d_ctr, s);
+          if (rc) {
+            if (err) *err = "scan fallback of the exact k-NN loop failed";
+            return rc;
+          }
+          MIH_CHECK(hipMemcpyAsync(h_ctr, d_ctr, 4, hipMemcpyDeviceToHost, s));
+          MIH_CHECK(hipStreamSynchronize(s));
+          if (trace) fprintf(stderr, "[vc_mih] shell r=%u: %u queries answered by the verify kernel (cost model), %u continue\n", r, n_cur - h_ctr[0], h_ctr[0]);
+          n_cur = h_ctr[0];
+          std::swap(cur, nxt);
+          switched = true;
+          if (n_cur == 0) break;
+        }
+      }
       const auto t_shell = std::chrono::steady_clock::now();
       ProbeParams p{};
       p.cols = d_cols; p.stride = stride; p.tables = ix->d_tables; p.queries = d_q + (size_t)q0 * ix->W;
@@ -2781,6 +3317,15 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
     for (uint32_t r = 0; r <= rsub; ++r) probes += (uint64_t)tables_at(r) * binom_host(ix->sbits, r);
     const double avg_bucket = (double)ix->n / (ix->sbits >= 32 ? 4294967296.0 : (double)(1ull << ix->sbits));
     inblock = probes <= MQ_RADIUS_BUDGET && rsub <= 16 && (double)probes * avg_bucket <= MQ_ENTRY_BUDGET;
+    if (ix->knobs.mih_stream == 2 && ix->sbits <= 16) inblock = false;   // tests: small databases through the streaming kernel too
+  }
+  // <= 16-bit substrings whose shells exceed the query kernel's entry budget: stream the buckets (mih_bucket_stream_kernel)
+  uint32_t stream_probes = 0;
+  bool stream = false;
+  if (use_mih && !inblock && ix->knobs.mih_host_loop == 0 && ix->knobs.mih_stream != 0 && ix->sbits <= 16) {
+    for (uint32_t r = 0; r <= rsub; ++r) stream_probes += tables_at(r) * binom_host(ix->sbits, r);
+    stream = stream_probes <= MS_MAXP;
+    for (const VcTableView& tv : ix->h_tables) stream = stream && tv.bcodes != nullptr;
   }
   const uint32_t TQ = use_mih ? MIH_RADIUS_TILE : 64u;
   uint32_t cap = std::max(wk->cap, use_mih ? std::max(ix->cap, 4096u) : 65536u);
@@ -2834,6 +3379,17 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
           qp.buf_entries = 2048;
           R_CHECK(timed_query_launch(ix, qp, W, qt, s));
           sorted_flag = d_sorted;
+        } else if (stream) {
+          uint32_t* list = ix->d_lists;
+          hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, list, vc_pack(radius + 1, 0));
+          R_CHECK(hipGetLastError());
+          StreamParams sp{};
+          sp.queries = d_q + (size_t)q0 * W; sp.tables = ix->d_tables; sp.ring = wk->d_ring; sp.count = d_count; sp.n = ix->n;
+          sp.m = ix->m; sp.sbits = ix->sbits; sp.id_base = id_base; sp.flags = ix->flags; sp.cap = cap; sp.radius = radius;
+          sp.rsub = rsub; sp.n_big = n_big; sp.small_shells = small_shells; sp.nprobes = stream_probes;
+          // enough blocks to fill the chip when the batch is small: a query's probe list is dealt out to `split` blocks
+          sp.split = std::max(1u, std::min(std::min(stream_probes, 64u), (8 * n_cu + qt - 1) / qt));
+          R_CHECK(timed_stream_launch(ix, sp, W, qt, s));
         } else {
           uint32_t* list = ix->d_lists;
           hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, list, vc_pack(radius + 1, 0));

@@ -16,10 +16,57 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
 // sums and resets the measurement records of mih_query_kernel: device time of its launches (HIP events on the launch
 // stream) and the algorithmic work counters {bucket probes, non-empty buckets, bucket entries verified, queries}
 void vc_mih_timing(VcMihIndex* ix, float* ms, uint32_t* launches, uint64_t totals[4], hipStream_t s);
+// Cost-model switch of the exact k-NN loop (the reference loops blindly to radius 32, search_worker.cc:170):
+// when the shells a query still has to probe cost more than streaming the shard once, the engine answers it with the
+// verify kernel and REPLAYS the stop rule of search_worker.cc:201-205 on the scan's candidates, so that results and
+// statistics are those of the radius loop.  Where a resolved query is left: the front of its candidate ring + the
+// statistics arrays of the search tile (mih_export_kernel and the statistics read-back then treat it like any other).
+struct VcMihScanTarget {
+  uint64_t* ring;            // [slot][cap]
+  uint32_t cap;
+  uint32_t* count;           // [slot] results written to the ring front
+  uint32_t* radius;          // [slot] last shell the radius loop would have searched
+  unsigned long long* seen;  // [slot] distinct items that loop would have verified (only when want_stats)
+  unsigned long long* sub;   // [slot] table 0's bucket gets (closed form: every leaf of shells 0..radius)
+  unsigned long long* loc;   // [slot] 0 (no bitmap attached on this path)
+};
+// d_q: the tile's queries ([slot][W]); d_list[0..n): slots to answer; d_unresolved / d_n_unresolved: slots the scan could
+// not settle (ring overflow, too many ties) -- they continue in the radius loop.  Enqueued on s, no host sync.
+typedef int (*vc_mih_scan_fn)(void* ctx, const uint64_t* d_q, const uint32_t* d_list, uint32_t n, uint32_t k, uint32_t stop_mult,
+                              const VcMihScanTarget& tgt, bool want_stats, uint32_t* d_unresolved, uint32_t* d_n_unresolved,
+                              hipStream_t s);
+struct VcMihScanFallback {
+  vc_mih_scan_fn fn = nullptr;
+  void* ctx = nullptr;
+  uint32_t n_cu = 0;
+};
+// kernels of that switch (vc_mih.hip), launched by the engine between its select and recover launches
+hipError_t vc_launch_gather_queries(const uint64_t* d_q, const uint32_t* d_list, uint32_t n, uint32_t W, uint64_t* d_out, hipStream_t s);
+struct VcMihReplayArgs {
+  const uint64_t* lin_ring;   // [gq][lin_cap] candidate rings of the scan (complete: every item at or below the k-th distance)
+  const uint32_t* lin_count;  // raw ring cursors, lin_qs words apart
+  const uint64_t* rows;       // [gq][k] select output (ascending, INF padded)
+  const uint32_t* rows_cnt;   // [gq] (UINT32_MAX = ring overflowed)
+  const uint64_t* queries;    // [gq][W] gathered queries
+  const uint32_t* list;       // [gq] slots
+  const uint64_t* cols;
+  uint64_t stride;
+  uint32_t lin_cap, lin_qs, gq, k, m, sbits, W, stop_mult, id_base;
+  VcMihScanTarget tgt;
+  uint32_t* unresolved;
+  uint32_t* n_unresolved;
+  uint32_t* resolved_flag;    // [gq] 1 = settled here
+};
+hipError_t vc_launch_mih_replay(const VcMihReplayArgs& a, hipStream_t s);
+// seen[list[i]] = #{items whose minimum substring distance <= radius[list[i]]} for the queries with flag[i] != 0
+hipError_t vc_launch_minsub_count(const uint64_t* cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t m, uint32_t sbits,
+                                  const uint64_t* d_queries, const uint32_t* d_list, const uint32_t* d_flag, uint32_t nq,
+                                  const uint32_t* d_radius, unsigned long long* d_seen, uint32_t n_cu, hipStream_t s);
+
 // d_q [nq][W]; d_out [nq][k] ascending INF-padded; d_cnt [nq]; stats (host, may be null) filled after a sync.
 int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint64_t n, const uint64_t* d_q, uint32_t nq,
                   uint32_t k, bool approximate, uint64_t* d_out, uint32_t* d_cnt, vc_query_stats* stats, hipStream_t s,
-                  std::string* err);
+                  std::string* err, const VcMihScanFallback* fb = nullptr);
 int vc_mih_bucket(VcMihIndex* ix, uint32_t table, uint32_t index, std::vector<uint32_t>* local_ids, hipStream_t s,
                   std::string* err);
 int vc_mih_bitmap_test(VcMihIndex* ix, uint32_t table, uint32_t index, int* bit, hipStream_t s, std::string* err);
