@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--tables", default="2,4", help="workload c2: table counts to run (the first one is the line's value)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child run that measures roofline.traffic")
+    ap.add_argument("--uniform-queries", action="store_true", help="workload knn_mih: uniform random queries (the worst case of the radius "
+                    "loop: shells up to r ~ 8; answered through the cost-model switch to the verify kernel)")
     ap.add_argument("--no-extras", action="store_true", help="default line only: skip the short qt=32 / c2 / knn_mih measurements (`extras`)")
     args = ap.parse_args(argv)
     d = {"c3": (1e9, 128, 8, 30), "c2": (1e8, 64, 1024, 20), "c5shard": (5e8, 256, 4096, 4), "knn_mih": (1e8, 128, 4096, 10)}[args.workload]
@@ -105,18 +107,21 @@ def cpu_baseline_linear(args, n_total):
     # (oracle/vc_oracle.cc VcoPool: threads created once, every worker scans its id range for the whole query batch,
     # per-range heaps merged per query), in batches of the GPU step's size
     with vo.Pool() as pool:
+        # a bigger sample than the 1-thread leg's: every worker should stream megabytes per call, not kilobytes
+        big_n = int(min(n_total, 1 << 27))
+        big = pool.gen_codes(big_n, args.bits, args.seed) if big_n > sample_n else codes
         batch = max(1, min(args.queries, 64))
-        pool.linear_knn(codes[:200000], q[:batch], args.k)  # warm
+        pool.linear_knn(big[:1 << 20], q[:batch], args.k)  # warm
         t0 = time.perf_counter()
         done = 0
         while done + batch <= len(q) and time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
-            pool.linear_knn(codes, q[done:done + batch], args.k)
+            pool.linear_knn(big, q[done:done + batch], args.k)
             done += batch
         dt = time.perf_counter() - t0
-        res["allcores"] = {"value": done / dt * sample_n / n_total, "cores": pool.threads, "nproc": nproc,
-                           "items_per_s": done / dt * sample_n,
+        res["allcores"] = {"value": done / dt * big_n / n_total, "cores": pool.threads, "nproc": nproc,
+                           "items_per_s": done / dt * big_n,
                            "sample": "%d queries in batches of %d x first %d codes in %.1f s on a persistent pool of %d threads; scaled by N_sample/N"
-                                     % (done, batch, sample_n, dt, pool.threads)}
+                                     % (done, batch, big_n, dt, pool.threads)}
     return res
 
 
@@ -566,7 +571,7 @@ def _extra_mih(args, env, kind, steps=6):
     return {"workload": ("configs[1]: 64-bit, 1e8 codes, all neighbours within 8, MIH m=2, 1024 queries per call" if kind == "c2" else
                          "exact top-100 through MIH, 128-bit, 1e8 clustered codes, m=4, 4096 queries per call"),
             "value": Q * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3,
-            "kernel": "mih_query_kernel" if kind == "c2" else "mih_wave_kernel + mih_query_kernel",
+            "kernel": "mih_query_kernel",
             "kernel_ms_per_step": tm.mih_ms / steps, "kernel_launches_per_step": tm.mih_launches / steps,
             "algorithmic_bytes_per_step": (roof.get("algorithmic_bytes_per_launch") or 0) * tm.mih_launches / steps,
             "per_query": roof.get("per_query"), "results_check": "ok" if ok else "FAILED"}
@@ -581,6 +586,18 @@ def run_extras(args, env):
         except Exception as ex:   # an extra never takes the headline down with it; the failure is reported in its place
             out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     return out
+
+
+def _scan_or_mih_roofline(tm, bits):
+    """knn_mih: the MIH query kernel's record, plus the verify kernel's when the cost-model switch sent queries its way"""
+    r = _mih_roofline(tm, bits)
+    if tm.scan_launches:
+        avg = tm.scan_ms / tm.scan_launches
+        r["verify_kernel"] = {"kernel": "vc_scan_kernel", "launches": tm.scan_launches, "avg_launch_ms": avg,
+                              "algorithmic_bytes_per_launch": tm.scan_bytes / tm.scan_launches,
+                              "achieved": tm.scan_bytes / tm.scan_launches / (avg * 1e-3) / 1e9 if avg > 0 else 0.0, "unit": "GB/s",
+                              "frac": tm.scan_bytes / tm.scan_launches / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS if avg > 0 else 0.0}
+    return r
 
 
 def run_c2(args, env, emit):
@@ -672,7 +689,10 @@ def run_knn_mih(args, env, emit):
     e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
     e.add_synthetic(n, seed=args.seed, kind=vc.SYNTH_CLUSTERED, n_centres=max(n // 1000, 1), max_flips=11)
     e.build_index()
-    host_q = [_near_queries(e, n, Q, bits, 4, rng) for _ in range(2)]
+    if args.uniform_queries:
+        host_q = [rng.integers(0, 256, size=(Q, bits // 8), dtype=np.uint8) for _ in range(2)]
+    else:
+        host_q = [_near_queries(e, n, Q, bits, 4, rng) for _ in range(2)]
     dev_q = [torch.from_numpy(h).to(env.device) for h in host_q]
     d_out = torch.empty((Q, k), dtype=torch.int64, device=env.device)
     d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
@@ -701,9 +721,11 @@ def run_knn_mih(args, env, emit):
         "config": {
             "workload": "SearchWorker::find exact MIH: %d-bit codes, %.3g clustered codes (n/1000 centres, <= 11 flips), m=4 x 32-bit, top-%d" % (bits, n, k),
             "n_codes": n, "bits": bits, "k": k, "queries_per_step": Q, "seed": args.seed,
-            "query_kind": "DB item with 0-4 random bit flips", "api": "vc_search_knn_dev: queries and results resident in HBM",
+            "query_kind": "uniform random (radius loop would need shells up to r ~ 8: answered by the verify kernel through the cost-model "
+                          "switch, stop rule replayed)" if args.uniform_queries else "DB item with 0-4 random bit flips",
+            "api": "vc_search_knn_dev: queries and results resident in HBM",
         },
-        "roofline": _mih_roofline(tm, bits),
+        "roofline": _scan_or_mih_roofline(tm, bits),
         "results_check": "ok" if ok else "FAILED",
     }
     if not args.no_traffic:

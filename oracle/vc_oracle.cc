@@ -348,12 +348,17 @@ void vco_linear_knn_pool(void* pool, const uint8_t* codes, uint64_t n, uint32_t 
   P->run([&](uint32_t w) {
     const uint64_t lo = n * w / T, hi = n * (w + 1) / T;
     std::vector<std::priority_queue<uint64_t> > h(nq);
-    for (uint64_t i = lo; i < hi; ++i) {
-      const uint8_t* c = codes + i * nbytes;
+    // chunks of 4096 codes (cache resident), every query over the chunk in turn: the inner loop is linear_search.cc:44-57
+    for (uint64_t c0 = lo; c0 < hi; c0 += 4096) {
+      const uint64_t c1 = std::min<uint64_t>(hi, c0 + 4096);
       for (uint32_t q = 0; q < nq; ++q) {
-        const uint64_t v = pack((uint32_t)hamming32(c, queries + (size_t)q * nbytes, nbytes), id_base + (uint32_t)i);
-        if (h[q].size() < k) h[q].push(v);
-        else if (h[q].top() > v) { h[q].pop(); h[q].push(v); }
+        const uint8_t* qp = queries + (size_t)q * nbytes;
+        std::priority_queue<uint64_t>& hq = h[q];
+        for (uint64_t i = c0; i < c1; ++i) {
+          const uint64_t v = pack((uint32_t)hamming32(codes + i * nbytes, qp, nbytes), id_base + (uint32_t)i);
+          if (hq.size() < k) hq.push(v);
+          else if (hq.top() > v) { hq.pop(); hq.push(v); }
+        }
       }
     }
     for (uint32_t q = 0; q < nq; ++q) {

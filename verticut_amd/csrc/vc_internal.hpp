@@ -22,13 +22,12 @@ struct VcKnobs {
   int resident_mb = -1;                       // VC_SCAN_RESIDENT_MB: database prefix kept in the Infinity Cache by the verify pass (-1 = default)
   bool scan_trace = false;                    // VC_SCAN_TRACE=1 (diagnostic build): per-block start / end times of the verify kernel
   int mih_host_loop = 0;                      // VC_MIH_HOST_LOOP=1: one host round trip per shell (the round-1 loop)
+  int mih_phases = 0;                         // VC_MIH_PHASES=1 (dev): per-phase times of mih_query_kernel on stderr
   int mih_switch = 1;                         // VC_MIH_SWITCH=0: the exact k-NN loop never switches to the verify kernel; 2: always (tests)
   int mih_stream = 1;                         // VC_MIH_STREAM=0: radius search over <= 16-bit substrings through the per-shell probe kernels
   int tau_fold = 0;                           // VC_TAU_FOLD=1: small tiles cut the bootstrap histograms in the verify prologue instead of a
                                               // vc_tau_init_kernel launch (measured: the 1024 prologues cost 20 us, the launch 5 -- off)
-  int mih_wave = 1;                           // VC_MIH_WAVE=0: k-NN through the block-per-query kernel only (no mih_wave_kernel stage)
-  int mih_wave_shells = -1;                   // VC_MIH_WAVE_SHELLS: last shell run by mih_wave_kernel (-1 = automatic)
-  int mih_pair01 = 1;                         // VC_MIH_PAIR01=0: mih_wave_kernel scans shells 0 and 1 in separate passes
+  int mih_group = 0;                          // VC_MIH_GROUP=1..3: shells sharing the query kernel's first pass (0 = adaptive)
   uint32_t recover_spin_limit = 0;            // VC_RECOVER_SPIN_LIMIT: bound of the recovery grid barrier's spin (0 = default, ~3 s)
   uint32_t recover_test_fail = 0;             // VC_RECOVER_TEST_FAIL=N (tests): the first N recover launches wait for a block that never comes
 };

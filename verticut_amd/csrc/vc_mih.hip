@@ -41,10 +41,11 @@ struct VcTableView {
   const uint32_t* ids;
   const uint32_t* bitmap;
   const uint32_t* blockrank;  // s == 32 only
-  // s == 32 only: blockoff[b] = offsets[blockrank[b]], b = 0 .. 2^24 -- the entry position of block b's first key.  When a
-  // block's buckets all hold one entry (blockoff[b + 1] - blockoff[b] == its set bits: 93 % of the blocks at 1e8 codes)
-  // the position of a key's entry is blockoff[b] + (set bits below the key): one sector instead of blockrank + offsets.
-  const uint32_t* blockoff;
+  // s == 32 only: blockdir[b] = {offsets[blockrank[b]], blockrank[b]}, b = 0 .. 2^24 -- the entry position and the rank of
+  // block b's first key in ONE 8-byte record.  When a block's buckets all hold one entry (blockdir[b + 1].x - blockdir[b].x
+  // == its set bits: 93 % of the blocks at 1e8 uniform codes) the position of a key's entry is blockdir[b].x + (set bits
+  // below the key); otherwise the rank is already at hand and offsets[] is the only further round trip.
+  const uint2* blockoff;
   // Optional copy of the codes in THIS table's bucket order (word j of the pos-th entry at bcodes[j*n + pos]), built
   // for substrings <= 16 bit: their buckets hold thousands of items (1526 at 1e8 codes, s = 16), and verifying a
   // bucket through ids[] -> cols[] is an 8-byte gather per word that moves a 64-byte sector each; from the copy it is
@@ -124,9 +125,11 @@ __global__ void __launch_bounds__(256) mih_blockpop_kernel(const uint32_t* __res
 }
 
 __global__ void __launch_bounds__(256) mih_blockoff_kernel(const uint32_t* __restrict__ blockrank, const uint32_t* __restrict__ offsets,
-                                                           uint32_t nblocks, uint32_t n_unique, uint32_t* __restrict__ blockoff) {
-  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblocks; b += gridDim.x * blockDim.x)
-    blockoff[b] = offsets[b < nblocks ? blockrank[b] : n_unique];
+                                                           uint32_t nblocks, uint32_t n_unique, uint2* __restrict__ blockoff) {
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblocks; b += gridDim.x * blockDim.x) {
+    const uint32_t rk = b < nblocks ? blockrank[b] : n_unique;
+    blockoff[b] = make_uint2(offsets[rk], rk);
+  }
 }
 
 // ImageBitmap::get_idx (bitmap.cc:22-26)
@@ -582,7 +585,9 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 // distance.  A query that is not finished after shell r_last (the shells beyond cost > 10^5 probes) writes its state
 // to the slot arrays and joins the `heavy` list, which the multi-block kernels above continue from shell r_last + 1.
 // =============================================================================================================
+#ifndef MQ_BLK
 #define MQ_BLK 256u
+#endif
 #define MQ_G 4u                         // keys per thread per pass (<= 16-bit substrings)
 #define MQ_PASS (MQ_BLK * MQ_G)
 // 32-bit substrings: a key = (hi: 32 - LO bits | lo: LO bits), a granule = the 2^LO bitmap bits that share `hi`; LO is a
@@ -605,13 +610,20 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 #ifndef MQ_MINW
 #define MQ_MINW 4
 #endif
-#define MQ_ROUND (MQ_BLK * MIH_EPT)     // bucket entries verified per round
+#ifndef MQ_EPT
+#define MQ_EPT 4u                        // bucket entries per thread and round of the query kernel's verify phase
+#endif
+#define MQ_ROUND (MQ_BLK * MQ_EPT)      // bucket entries verified per round
 #define MQ_BW 17u                       // row width of the LDS binomial table: C(c, i), c <= 32, i <= 16
 #define MQ_MODE_EXACT 0u
 #define MQ_MODE_APPROX 1u
 #define MQ_MODE_RADIUS 2u
 
-#define MQ_TAG (1ull << 63)             // k-NN candidate of the second shell of a paired pass
+// k-NN candidates of a grouped first pass carry their shell (relative to the pass's first shell) in the two top bits:
+// dist << 32 | id uses 42 bits at most.  VC_PACK_INF reads as class 3, which no entry has, so padding sorts last.
+#define MQ_TAG_SHIFT 62
+#define MQ_TAG_MASK (3ull << MQ_TAG_SHIFT)
+#define MQ_MAX_GROUP 3u
 static __host__ __device__ inline uint32_t mq_hist_bins(uint32_t W) { return (W * 64u + 1u + 7u) & ~7u; }
 
 struct QueryKernelParams {
@@ -632,17 +644,21 @@ struct QueryKernelParams {
   uint32_t* heavy_ctr;
   uint64_t* out;               // k-NN: [nq][k] rows
   uint32_t* out_cnt;
-  // continuation of queries another kernel (mih_wave_kernel) left unfinished: block b serves slot_list[b] and resumes
-  // at shell r_first from the state that kernel handed over (st.topk / count / seen / sub / loc); null = fresh queries
-  const uint32_t* slot_list;
-  const uint32_t* slot_count;  // with slot_list: device counter of listed slots -- blocks beyond it leave at once, so the
-                               // continuation can be launched with an upper-bound grid and no host round trip in between
-  uint32_t r_first;
-  uint32_t nq;                 // mih_wave_kernel: queries of the launch (one wave each)
-  uint32_t pair01;             // mih_wave_kernel: scan shells 0 and 1 in one pass
+  unsigned long long* phase_dbg;  // dev (VC_MIH_PHASES): [8] phase times of mih_query_kernel, summed over the launch
+  uint32_t group;              // k-NN, 32-bit substrings: shells 0 .. group-1 share the first pass (1 = one shell per pass)
+  uint32_t* radius_hist;       // k-NN: [4] queries of the launch by the shell they stopped in (0, 1, 2, later / handed over)
 };
 
 __device__ __forceinline__ uint32_t mq_unrank(const uint32_t* sb, uint32_t j, uint32_t r, uint32_t s) {
+  // the shells that matter (r <= 2) in closed form: the table walk below is a chain of ~25 dependent LDS reads per flip
+  if (r == 0) return 0u;
+  if (r == 1) return 1u << j;
+  if (r == 2) {   // j = C(c2, 2) + c1, c1 < c2: c2 = floor((1 + sqrt(1 + 8 j)) / 2), corrected for rounding
+    uint32_t c2 = (uint32_t)((1.0f + __fsqrt_rn(1.0f + 8.0f * (float)j)) * 0.5f);
+    while (c2 * (c2 - 1) / 2 > j) --c2;
+    while ((c2 + 1) * c2 / 2 <= j) ++c2;
+    return (1u << c2) | (1u << (j - c2 * (c2 - 1) / 2));
+  }
   uint32_t mask = 0, c = s;
   for (uint32_t i = r; i >= 1; --i) {
     do { --c; } while (sb[c * MQ_BW + i] > j);   // largest c with C(c,i) <= j
@@ -674,11 +690,12 @@ __device__ __forceinline__ uint32_t mw_hist_cut(const uint32_t* h, uint32_t nbin
   return vc_wave_min(cand);
 }
 
-// ---- k-NN candidate buffer of mih_query_kernel: s_buf[0 .. *s_ncand) unsorted, entries of the second shell of a paired
-// pass tagged with MQ_TAG.  Rare paths, deliberately NOT inlined (all threads of the block call them together).
-// Drop what the threshold has overtaken (and, when asked, the tagged entries), in place, 256 entries at a time.
+// ---- k-NN candidate buffer of mih_query_kernel: s_buf[0 .. *s_ncand) unsorted, every entry tagged with its shell class
+// (MQ_TAG_MASK; class 0 = shells evaluated so far + the first shell of the pass).  Rare paths, deliberately NOT inlined
+// (all threads of the block call them together).
+// Drop what the threshold has overtaken and the classes above max_cls, in place, 256 entries at a time.
 __device__ __noinline__ void mq_compact(uint64_t* s_buf, uint32_t* s_ncand, const uint64_t* s_thresh, uint32_t* s_wsum,
-                                        uint32_t buf_entries, bool drop_tagged) {
+                                        uint32_t buf_entries, uint32_t max_cls, bool clear_tags) {
   const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
   __syncthreads();
   const uint32_t fill = min(*s_ncand, buf_entries);
@@ -687,7 +704,7 @@ __device__ __noinline__ void mq_compact(uint64_t* s_buf, uint32_t* s_ncand, cons
   for (uint32_t base = 0; base < fill; base += MQ_BLK) {
     const uint32_t i = base + tid;
     const uint64_t v = i < fill ? s_buf[i] : VC_PACK_INF;
-    const bool keep = i < fill && (v & ~MQ_TAG) < thr && !(drop_tagged && (v & MQ_TAG));
+    const bool keep = i < fill && (v & ~MQ_TAG_MASK) < thr && (uint32_t)(v >> MQ_TAG_SHIFT) <= max_cls;
     const uint64_t km = __ballot(keep);
     if (lane == 0) s_wsum[wave] = (uint32_t)__popcll(km);
     __syncthreads();                      // every thread has read its entry; the wave counts are visible
@@ -697,7 +714,7 @@ __device__ __noinline__ void mq_compact(uint64_t* s_buf, uint32_t* s_ncand, cons
       if (w < wave) before += s_wsum[w];
       total += s_wsum[w];
     }
-    if (keep) s_buf[nf + before + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = v;
+    if (keep) s_buf[nf + before + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = clear_tags ? (v & ~MQ_TAG_MASK) : v;
     nf += total;
     __syncthreads();
   }
@@ -705,9 +722,9 @@ __device__ __noinline__ void mq_compact(uint64_t* s_buf, uint32_t* s_ncand, cons
   __syncthreads();
 }
 
-// Exact selection when ties overfill the buffer: sort (tagged entries behind the untagged ones) and keep the k best of
-// either kind -- a superset of the top-k of the first shell alone and of both shells together.
-__device__ __noinline__ void mq_select_exact(uint64_t* s_buf, uint32_t* s_ncand, uint64_t* s_thresh, uint32_t* s_tmp,
+// Exact selection when ties overfill the buffer: sort (class-major: the tag sits in the top bits) and keep the k best of
+// every class -- a superset of the top-k of each prefix of shells the stop rule may still be evaluated for.
+__device__ __noinline__ void mq_select_exact(uint64_t* s_buf, uint32_t* s_ncand, uint64_t* s_thresh, uint32_t* s_tmp /*[4]*/,
                                              uint32_t buf_entries, uint32_t k) {
   const uint32_t tid = threadIdx.x;
   __syncthreads();
@@ -716,24 +733,27 @@ __device__ __noinline__ void mq_select_exact(uint64_t* s_buf, uint32_t* s_ncand,
   while (P < fill) P <<= 1;
   for (uint32_t i = fill + tid; i < P; i += MQ_BLK) s_buf[i] = VC_PACK_INF;
   vc_bitonic_lds(s_buf, P, MQ_BLK);
-  uint32_t mine = 0;
-  for (uint32_t i = tid; i < fill; i += MQ_BLK) mine += !(s_buf[i] & MQ_TAG);
-  if (tid == 0) *s_tmp = 0;
+  if (tid < 4) s_tmp[tid] = 0;
   __syncthreads();
-  if (mine) atomicAdd(s_tmp, mine);
+  for (uint32_t i = tid; i < fill; i += MQ_BLK) atomicAdd(&s_tmp[(uint32_t)(s_buf[i] >> MQ_TAG_SHIFT)], 1u);
   __syncthreads();
-  const uint32_t nU = *s_tmp;
-  const uint32_t keepU = min(nU, k), keepT = min(fill - nU, k);
-  for (uint32_t base = 0; base < keepT; base += MQ_BLK) {   // tagged survivors move up behind the untagged ones
-    const uint32_t i = base + tid;
-    const uint64_t v = i < keepT ? s_buf[nU + i] : 0;
-    __syncthreads();
-    if (i < keepT) s_buf[keepU + i] = v;
-    __syncthreads();
+  const uint32_t n0 = s_tmp[0], n1 = s_tmp[1], n2 = s_tmp[2];
+  const uint32_t k0 = min(n0, k), k1 = min(n1, k), k2 = min(n2, k);
+  __syncthreads();
+  // the kept entries of classes 1 and 2 move up behind those of the class before (destination <= source: in order, in chunks)
+  for (uint32_t c = 1; c <= 2; ++c) {
+    const uint32_t src = c == 1 ? n0 : n0 + n1, dst = c == 1 ? k0 : k0 + k1, cnt = c == 1 ? k1 : k2;
+    for (uint32_t base = 0; base < cnt; base += MQ_BLK) {
+      const uint32_t i = base + tid;
+      const uint64_t v = i < cnt ? s_buf[src + i] : 0;
+      __syncthreads();
+      if (i < cnt) s_buf[dst + i] = v;
+      __syncthreads();
+    }
   }
   if (tid == 0) {
-    *s_ncand = keepU + keepT;
-    if (nU >= k && s_buf[k - 1] + 1 < *s_thresh) *s_thresh = s_buf[k - 1] + 1;   // exact bound for everything still to come
+    *s_ncand = k0 + k1 + k2;
+    if (n0 >= k && s_buf[k - 1] + 1 < *s_thresh) *s_thresh = s_buf[k - 1] + 1;   // exact bound for everything still to come
   }
   __syncthreads();
 }
@@ -753,14 +773,14 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   uint32_t* s_binom = s_meta + MQ_HMAX;                      // [33][MQ_BW]
   uint32_t* s_mask = s_binom + 33 * MQ_BW;                   // [m][MQ_NJ][MQ_GW] (32-bit substrings only)
   const uint32_t HB = mq_hist_bins(W);
-  uint32_t* s_hist = s_mask + (p.sbits == 32 ? p.m * (MQ_LO_MAX + 1) * ((1u << MQ_LO_MAX) / 32u) : 0u);   // [2][HB] (k-NN modes)
-  __shared__ VcTableView s_tv[64];
-  __shared__ uint32_t s_nh, s_ncand, s_seen, s_seenB, s_hits0, s_hits0B, s_dk, s_wsum[MQ_BLK / VC_WAVE];
+  uint32_t* s_hist = s_mask + (p.sbits == 32 ? p.m * (MQ_LO_MAX + 1) * ((1u << MQ_LO_MAX) / 32u) : 0u);   // [MQ_MAX_GROUP][HB] (k-NN modes)
+  VcTableView* s_tv = (VcTableView*)(((uintptr_t)(s_hist + MQ_MAX_GROUP * HB) + 15) & ~(uintptr_t)15);      // [m]
+  // s_seenc / s_hits0c [class]: distinct items verified / table 0's set leaves, per shell class of the current pass
+  __shared__ uint32_t s_nh, s_ncand, s_seenc[MQ_MAX_GROUP], s_hits0c[MQ_MAX_GROUP], s_dk, s_wsum[MQ_BLK / VC_WAVE < 4 ? 4 : MQ_BLK / VC_WAVE];   // (s_wsum doubles as the 4 class counters of mq_select_exact)
   __shared__ uint32_t s_segstart[28], s_segh[27], s_segmask[27], s_segr[27], s_nseg;
   __shared__ uint64_t s_thresh;
 
-  if (p.slot_count && blockIdx.x >= *p.slot_count) return;
-  const uint32_t slot = p.slot_list ? p.slot_list[blockIdx.x] : blockIdx.x;
+  const uint32_t slot = blockIdx.x;
   const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
   const uint32_t s = p.sbits, m = p.m;
   const uint32_t smask = s == 32 ? 0xFFFFFFFFu : ((1u << s) - 1u);
@@ -783,14 +803,14 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   if (s == 32)
     for (uint32_t i = tid; i < m * MQ_NJ * MQ_GW; i += MQ_BLK) s_mask[i] = 0;
   if (knn)
-    for (uint32_t i = tid; i < 2 * HB; i += MQ_BLK) s_hist[i] = 0;
+    for (uint32_t i = tid; i < MQ_MAX_GROUP * HB; i += MQ_BLK) s_hist[i] = 0;
+  if (tid < MQ_MAX_GROUP) {
+    s_seenc[tid] = 0;
+    s_hits0c[tid] = 0;
+  }
   if (tid == 0) {
     s_nh = 0;
     s_ncand = 0;
-    s_seen = 0;
-    s_seenB = 0;
-    s_hits0 = 0;
-    s_hits0B = 0;
     s_thresh = knn ? VC_PACK_INF : vc_pack(p.radius + 1, 0);
   }
   __syncthreads();
@@ -814,11 +834,23 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     }
   }
 
-  // k-NN modes keep s_buf UNSORTED: s_buf[0 .. s_ncand) = the candidates that passed the running threshold, those of
-  // the second shell of a paired pass tagged with MQ_TAG.  The stop rule's k-th distance and the threshold come from a
+  // k-NN modes keep s_buf UNSORTED: s_buf[0 .. s_ncand) = the candidates that passed the running threshold, tagged with
+  // their shell class inside a grouped pass (MQ_TAG_MASK).  The stop rule's k-th distance and the threshold come from a
   // distance histogram in LDS (no sort per shell: the bitonic network after every shell was most of this kernel's
   // instructions); the buffer is compacted when it fills and sorted once, when the query ends or is handed over.
-  uint32_t r_tag = 0xFFFFFFFFu;    // substring distance that marks the second shell of a paired pass (block-uniform)
+  // VC_MIH_PHASES (dev): where a block's time goes -- phase times in 10 ns ticks, summed per phase over the launch
+  __shared__ unsigned long long s_ph_last;
+  __shared__ uint32_t s_ph_cur;
+  auto tick = [&](uint32_t next) {   // ends the current phase, starts `next`
+    if (p.phase_dbg && tid == 0) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      atomicAdd(&p.phase_dbg[s_ph_cur], now - s_ph_last);
+      s_ph_last = now;
+      s_ph_cur = next;
+    }
+  };
+  if (p.phase_dbg && tid == 0) { s_ph_last = __builtin_amdgcn_s_memrealtime(); s_ph_cur = 1; }
+  uint32_t r_base = 0;             // first shell of the current pass: a candidate's class = its substring distance - r_base (block-uniform)
   uint32_t kk = 0;                 // radius mode: sorted results in s_buf[0..kk)           (block-uniform)
   bool spilled = false;            // radius mode: results went to the global ring unsorted (block-uniform)
   uint32_t ring_fill = 0;          // radius mode: entries already in the global ring       (block-uniform)
@@ -863,12 +895,23 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 
   // ---- k-NN: rare paths of the candidate buffer live in functions of their own (mq_compact / mq_select_exact): inlined
   // into every drain() they made the compiler outline drain() itself, closure and all
-  auto compact = [&](bool drop_tagged) { mq_compact(s_buf, &s_ncand, &s_thresh, s_wsum, p.buf_entries, drop_tagged); };
-  auto select_exact = [&]() { mq_select_exact(s_buf, &s_ncand, &s_thresh, &s_dk, p.buf_entries, p.k); };
+  auto compact = [&](uint32_t max_cls, bool clear_tags) { mq_compact(s_buf, &s_ncand, &s_thresh, s_wsum, p.buf_entries, max_cls, clear_tags); };
+  auto select_exact = [&]() { mq_select_exact(s_buf, &s_ncand, &s_thresh, s_wsum, p.buf_entries, p.k); };
   // ---- k-NN: sorted top-k of what the evaluated shells have seen -> s_buf[0 .. return value)
-  auto finish_sort = [&]() -> uint32_t {
-    compact(true);
+  auto finish_sort = [&](uint32_t max_cls) -> uint32_t {
+    compact(max_cls, true);
     const uint32_t fill = s_ncand;
+    if (fill <= MQ_BLK) {
+      // the usual case (k + ties survive the final threshold): order by counting -- entry i goes to slot #{j : a[j] < a[i]},
+      // packed values are distinct -- fill broadcast LDS reads and two barriers instead of a 36-stage network
+      const uint64_t v = tid < fill ? s_buf[tid] : VC_PACK_INF;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < fill; ++j) rank += s_buf[j] < v;
+      __syncthreads();
+      if (tid < fill) s_buf[rank] = v;
+      __syncthreads();
+      return min(fill, p.k);
+    }
     uint32_t P = 2;
     while (P < fill) P <<= 1;
     for (uint32_t i = fill + tid; i < P; i += MQ_BLK) s_buf[i] = VC_PACK_INF;
@@ -879,6 +922,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   // ---- drain the hit list: (rank -> offsets), prefix sum, balanced verify
   auto drain = [&]() __attribute__((always_inline)) {
     __syncthreads();
+    tick(2);
     const uint32_t H = min(s_nh, MQ_HMAX);
     if (s == 32) {
       for (uint32_t i = tid; i < H; i += MQ_BLK) {
@@ -894,13 +938,13 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           all += __popc(wv);
           below += j < wq ? __popc(wv) : (j == wq ? __popc(wv & ((1u << (key & 31)) - 1u)) : 0u);
         }
-        const uint32_t o0 = tv.blockoff[blk], o1 = tv.blockoff[blk + 1];
+        const uint2 d0 = tv.blockoff[blk], d1 = tv.blockoff[blk + 1];
         uint32_t a, len;
-        if (o1 - o0 == all) {          // every bucket of the block holds one entry
-          a = o0 + below;
+        if (d1.x - d0.x == all) {      // every bucket of the block holds one entry
+          a = d0.x + below;
           len = 1;
         } else {
-          const uint32_t rk = tv.blockrank[blk] + below;
+          const uint32_t rk = d0.y + below;
           a = tv.offsets[rk];
           len = tv.offsets[rk + 1] - a;
         }
@@ -937,8 +981,9 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     __syncthreads();
     w_hits += H;
     w_entries += total;
+    tick(3);
 
-    uint32_t seen_acc = 0, seen_accB = 0;
+    uint32_t seen_acc = 0, seen_acc1 = 0, seen_acc2 = 0;   // per shell class (wave-uniform)
     for (uint32_t e0 = 0; e0 < total; e0 += MQ_ROUND) {
       // room for one round of survivors behind what the buffer already holds.  The fill is read between two barriers:
       // the first ends the previous round's appends, the second keeps a fast wave's appends of THIS round from being
@@ -948,18 +993,18 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       __syncthreads();
       if (kk + fill + MQ_ROUND > p.buf_entries) {
         if (knn) {
-          compact(false);
+          compact(MQ_MAX_GROUP, false);
           if (s_ncand + MQ_ROUND > p.buf_entries) select_exact();
         } else {
           flush_ring();
         }
       }
       const uint64_t thresh = s_thresh;
-      uint32_t local[MIH_EPT], meta[MIH_EPT];
-      uint64_t x[MIH_EPT][W];
-      bool live[MIH_EPT];
+      uint32_t local[MQ_EPT], meta[MQ_EPT];
+      uint64_t x[MQ_EPT][W];
+      bool live[MQ_EPT];
 #pragma unroll
-      for (uint32_t g = 0; g < MIH_EPT; ++g) {
+      for (uint32_t g = 0; g < MQ_EPT; ++g) {
         const uint32_t e = e0 + g * MQ_BLK + tid;
         live[g] = e < total;
         const uint32_t ec = live[g] ? e : 0;
@@ -991,7 +1036,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         }
       }
 #pragma unroll
-      for (uint32_t g = 0; g < MIH_EPT; ++g) {
+      for (uint32_t g = 0; g < MQ_EPT; ++g) {
         bool emit = live[g];
         uint64_t packed = 0;
         if (live[g]) {
@@ -1014,10 +1059,11 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         }
         const uint64_t emask = __ballot(emit);
         if (emask == 0) continue;
-        const bool second = (meta[g] >> 8) == r_tag;     // candidate of the second shell of a paired pass
-        const uint64_t bmask = __ballot(emit && second);
-        seen_accB += (uint32_t)__popcll(bmask);
-        seen_acc += (uint32_t)__popcll(emask & ~bmask);
+        const uint32_t cls = knn ? (meta[g] >> 8) - r_base : 0u;   // shell class inside a grouped pass (0 for single-shell passes)
+        const uint64_t m1 = __ballot(emit && cls == 1), m2 = __ballot(emit && cls == 2);
+        seen_acc1 += (uint32_t)__popcll(m1);
+        seen_acc2 += (uint32_t)__popcll(m2);
+        seen_acc += (uint32_t)__popcll(emask & ~(m1 | m2));
         const bool keep = emit && packed < thresh;
         const uint64_t kmask = __ballot(keep);
         if (kmask == 0) continue;
@@ -1025,16 +1071,18 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         if (lane == 0) base = atomicAdd(&s_ncand, (uint32_t)__popcll(kmask));
         base = __builtin_amdgcn_readfirstlane(base);
         if (keep) {
-          s_buf[kk + base + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull))] = second ? (packed | MQ_TAG) : packed;
-          if (knn) atomicAdd(&s_hist[(second ? HB : 0u) + (uint32_t)(packed >> 32)], 1u);
+          s_buf[kk + base + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull))] = packed | ((uint64_t)cls << MQ_TAG_SHIFT);
+          if (knn) atomicAdd(&s_hist[cls * HB + (uint32_t)(packed >> 32)], 1u);
         }
       }
     }
-    if (lane == 0 && seen_acc) atomicAdd(&s_seen, seen_acc);
-    if (lane == 0 && seen_accB) atomicAdd(&s_seenB, seen_accB);
+    if (lane == 0 && seen_acc) atomicAdd(&s_seenc[0], seen_acc);
+    if (lane == 0 && seen_acc1) atomicAdd(&s_seenc[1], seen_acc1);
+    if (lane == 0 && seen_acc2) atomicAdd(&s_seenc[2], seen_acc2);
     __syncthreads();
     if (tid == 0) s_nh = 0;
     __syncthreads();
+    tick(1);
   };
 
   // ---- one shell (or the whole ball) of ALL tables, 32-bit substrings: granule scan over the segments in s_seg*.
@@ -1080,7 +1128,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           const uint32_t qk = qkey(t);
           gr[g] = (qk >> MQ_LO) ^ hi;
           qlo[g] = qk & ((1u << MQ_LO) - 1u);
-          meta0[g] = t | (s_segh[seg] << 8) | (s_segr[seg] == r_tag ? 0x80000000u : 0u);
+          meta0[g] = t | (s_segh[seg] << 8) | ((s_segr[seg] - r_base) << 30);   // bits 30..31: shell class of the segment
           mi[g] = t * MQ_NJ + s_segmask[seg];
           const uint4* gp = reinterpret_cast<const uint4*>(s_tv[t].bitmap + (uint64_t)gr[g] * MQ_GW);
 #pragma unroll
@@ -1088,7 +1136,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         }
       }
       uint32_t w[MQ_G32][MQ_GW];
-      uint32_t cnt = 0, cnt0 = 0, cnt0b = 0;
+      uint32_t cnt = 0, cnt0[MQ_MAX_GROUP] = {0, 0, 0};
 #pragma unroll
       for (uint32_t g = 0; g < MQ_G32; ++g) {
         const uint32_t* mk = s_mask + mi[g] * MQ_GW;
@@ -1103,15 +1151,17 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         }
         cnt += c;
         if ((meta0[g] & 0xFFu) == 0 && tb_first == 0 && idx0 + g < per_table) {
-          if (meta0[g] >> 31) cnt0b += c; else cnt0 += c;
+#pragma unroll
+          for (uint32_t cc = 0; cc < MQ_MAX_GROUP; ++cc) cnt0[cc] += (meta0[g] >> 30) == cc ? c : 0u;
         }
       }
       if (p.flags & VC_FLAG_USE_BITMAP) {   // n_sub_reads_ of table 0 = its leaves whose bit is set (search_worker.cc:238-245)
-        uint32_t wt, wtb;
-        (void)vc_wave_excl_scan(cnt0, wt);
-        (void)vc_wave_excl_scan(cnt0b, wtb);
-        if (lane == 0 && wt) atomicAdd(&s_hits0, wt);
-        if (lane == 0 && wtb) atomicAdd(&s_hits0B, wtb);
+#pragma unroll
+        for (uint32_t cc = 0; cc < MQ_MAX_GROUP; ++cc) {
+          uint32_t wt;
+          (void)vc_wave_excl_scan(cnt0[cc], wt);
+          if (lane == 0 && wt) atomicAdd(&s_hits0c[cc], wt);
+        }
       }
       for (;;) {   // append this pass's hits; what does not fit waits for a drain
         if (!__syncthreads_or(cnt != 0)) break;
@@ -1188,7 +1238,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       if (p.flags & VC_FLAG_USE_BITMAP) {
         uint32_t wt;
         (void)vc_wave_excl_scan(cnt0, wt);
-        if (lane == 0 && wt) atomicAdd(&s_hits0, wt);
+        if (lane == 0 && wt) atomicAdd(&s_hits0c[0], wt);
       }
       for (;;) {
         if (!__syncthreads_or(cnt != 0)) break;
@@ -1238,25 +1288,6 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   };
 
   const uint32_t S = s;            // loop bound radius <= n_local_bytes_ * 8 (search_worker.cc:170)
-  if (knn && p.r_first) {          // resume: the state mih_wave_kernel handed over after shell r_first - 1
-    const uint32_t kin = min(p.st.count[slot], p.k);
-    for (uint32_t i = tid; i < kin; i += MQ_BLK) {
-      const uint64_t v = p.st.topk[(uint64_t)slot * p.k + i];
-      s_buf[i] = v;
-      atomicAdd(&s_hist[(uint32_t)(v >> 32)], 1u);
-    }
-    sub = p.st.sub[slot];
-    loc = p.st.loc[slot];
-    if (tid == 0) {
-      s_ncand = kin;
-      s_seen = (uint32_t)p.st.seen[slot];
-      // the hand-over threshold is the k-th best itself ("append iff better", the multi-block kernels' rule, which keep
-      // the committed top-k apart); here the committed entries live in the same buffer, so the bound is exclusive
-      const uint64_t th = p.st.thresh[slot];
-      s_thresh = th == VC_PACK_INF ? th : th + 1;
-    }
-    __syncthreads();
-  }
   if (!knn) {
     // fixed-radius neighbour search, every item within the full distance R kept.  Pigeonhole with the sharper radii of
     // multi-index hashing: R = m q + a  =>  tables 0..a search substring radius q, tables a+1..m-1 only q - 1 (were every
@@ -1303,11 +1334,12 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     return;
   }
 
-  for (uint32_t r = p.r_first; r <= p.r_last;) {
-    // shells 0 and 1 of 32-bit substrings share ONE pass (their 1 + 26 granules per table): the candidates of shell 1 are
-    // tagged and counted apart, the stop rule is evaluated for shell 0 alone first -- one scan / drain round less
-    const uint32_t r_hi = (s == 32 && r == 0 && p.pair01 && p.r_last >= 1) ? 1u : r;
-    r_tag = r_hi != r ? r_hi : 0xFFFFFFFFu;
+  for (uint32_t r = 0; r <= p.r_last;) {
+    // The first pass of 32-bit substrings covers shells 0 .. group-1 at once (their 1 + 26 (+ 326) granules per table):
+    // candidates are tagged with their shell class and counted per class, the stop rule is evaluated shell by shell
+    // afterwards -- no result or statistic changes, a scan / drain round is saved per grouped shell
+    const uint32_t r_hi = (s == 32 && r == 0) ? min(p.group ? p.group - 1 : 0u, min(p.r_last, MQ_MAX_GROUP - 1)) : r;
+    r_base = r;
     if (s == 32) {
       plan32(r, r_hi, false);
       scan32();
@@ -1316,21 +1348,20 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     }
     if (s_nh) drain();
     __syncthreads();
+    tick(4);
     for (uint32_t rr = r; rr <= r_hi; ++rr) {
-      if (rr != r) {                 // second shell of the pass: its candidates join the evaluated set
+      const uint32_t cls = rr - r;
+      if (cls) {                     // next shell of the pass: its candidates join the evaluated set (class 0 counters)
         for (uint32_t i = tid; i < HB; i += MQ_BLK) {
-          s_hist[i] += s_hist[HB + i];
-          s_hist[HB + i] = 0;
+          s_hist[i] += s_hist[cls * HB + i];
+          s_hist[cls * HB + i] = 0;
         }
-        const uint32_t fill = min(s_ncand, p.buf_entries);
-        for (uint32_t i = tid; i < fill; i += MQ_BLK) s_buf[i] &= ~MQ_TAG;
         if (tid == 0) {
-          s_seen += s_seenB;
-          s_seenB = 0;
-          s_hits0 = s_hits0B;
-          s_hits0B = 0;
+          s_seenc[0] += s_seenc[cls];
+          s_seenc[cls] = 0;
+          s_hits0c[0] = s_hits0c[cls];
+          s_hits0c[cls] = 0;
         }
-        r_tag = 0xFFFFFFFFu;
         __syncthreads();
       }
       // get_stat counters of table 0 (rank 0's, search_worker.cc:24-30): every leaf is a bitmap test when the bitmap
@@ -1339,13 +1370,13 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       w_probes += leaves * m;
       if (p.flags & VC_FLAG_USE_BITMAP) {
         loc += leaves;
-        sub += s_hits0;
+        sub += s_hits0c[0];
       } else {
         sub += leaves;
       }
-      const uint32_t seen = s_seen;
+      const uint32_t seen = s_seenc[0];
       __syncthreads();
-      if (tid == 0) s_hits0 = 0;
+      if (tid == 0) s_hits0c[0] = 0;
       if (wave == 0) {               // k-th distance among the candidates of the shells evaluated so far
         const uint32_t cut = seen >= p.k ? mw_hist_cut(s_hist, W * 64u + 1u, p.k) : 0xFFFFFFFFu;
         if (lane == 0) s_dk = cut;
@@ -1357,8 +1388,13 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         stop = seen >= p.k * MIH_APPROX_FACTOR;
       else                            // search_worker.cc:201-205: size == k && top.dist <= radius * 4 (radius already incremented)
         stop = dk != 0xFFFFFFFFu && dk <= (rr + 1) * p.stop_mult;
+      if (tid == 0 && dk != 0xFFFFFFFFu) {   // everything farther than the k-th distance is out for good
+        const uint64_t bnd = ((uint64_t)dk + 1) << 32;
+        if (bnd < s_thresh) s_thresh = bnd;
+      }
       if (stop || rr == S) {
-        const uint32_t kout = finish_sort();
+        tick(5);
+        const uint32_t kout = finish_sort(cls);   // classes beyond the shell the loop stops in were never seen by it
         put_work();
         for (uint32_t i = tid; i < p.k; i += MQ_BLK) p.out[(uint64_t)slot * p.k + i] = i < kout ? s_buf[i] : VC_PACK_INF;
         if (tid == 0) {
@@ -1367,527 +1403,39 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           p.st.seen[slot] = seen;
           p.st.sub[slot] = sub;
           p.st.loc[slot] = loc;
+          if (p.radius_hist) atomicAdd(&p.radius_hist[min(rr, 3u)], 1u);
         }
+        tick(6);
         return;
-      }
-      if (tid == 0 && dk != 0xFFFFFFFFu) {   // everything farther than the k-th distance is out for good
-        const uint64_t bnd = ((uint64_t)dk + 1) << 32;
-        if (bnd < s_thresh) s_thresh = bnd;
       }
       __syncthreads();
     }
+    if (r_hi != r) {                 // the pass is over: its candidates are ordinary (class 0) entries from now on
+      const uint32_t fill = min(s_ncand, p.buf_entries);
+      for (uint32_t i = tid; i < fill; i += MQ_BLK) s_buf[i] &= ~MQ_TAG_MASK;
+      __syncthreads();
+    }
+    tick(1);
     r = r_hi + 1;
   }
+  tick(5);
   // not finished: hand the query to the multi-block shells (state exactly as mih_commit_kernel leaves it)
-  const uint32_t kout = finish_sort();
+  const uint32_t kout = finish_sort(0);
   put_work();
   for (uint32_t i = tid; i < kout; i += MQ_BLK) p.st.topk[(uint64_t)slot * p.k + i] = s_buf[i];   // mih_seed_ring_kernel moves it into the ring
   if (tid == 0) {
     p.st.count[slot] = kout;
     p.st.prev[slot] = kout;
     p.st.thresh[slot] = kout == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
-    p.st.seen[slot] = s_seen;
+    p.st.seen[slot] = s_seenc[0];
     p.st.sub[slot] = sub;
     p.st.loc[slot] = loc;
     p.st.radius[slot] = 0;
     p.st.topn[slot] = kout;
     p.heavy_list[atomicAdd(p.heavy_ctr, 1u)] = slot;
+    if (p.radius_hist) atomicAdd(&p.radius_hist[3], 1u);
   }
 }
-
-// =============================================================================================================
-// mih_wave_kernel -- ONE WAVE runs a query's radius loop (32-bit substrings, k-NN modes, shells 0..r_last).
-//
-// The block-per-query kernel above spends a near-duplicate query's life waiting: 256 threads for the 108 granules of
-// shells 0 + 1, a workgroup barrier around every phase, a 55-stage bitonic network after every shell, four queries
-// resident per CU.  A query's work is a latency chain (granule -> block directory -> record), so the way to more
-// queries per second is more queries in flight: here a query owns 64 lanes and ~8 KB of LDS, 16 queries are resident
-// per CU, and nothing in the loop needs a workgroup barrier (a wave runs in lock step; LDS operations of one wave
-// complete in order).  Differences to the block kernel, none of them visible in results or statistics:
-//   * shells 0 and 1 are scanned in ONE pass (their 1 + 26 granules per table): candidates of shell 1 carry a tag bit
-//     and their own histogram / seen counter, the stop rule is first evaluated on shell 0's candidates alone
-//     (search_worker.cc:201-205), then the tags are cleared and it is evaluated for shell 1 -- one memory round trip
-//     less for every query that needs a second shell;
-//   * no sort per shell: the k-th distance of the stop rule and the append threshold come from a distance histogram in
-//     LDS (cut = smallest d whose cumulative count reaches k); entries beyond the threshold are compacted away only
-//     when the buffer fills, and the buffer is sorted once, when the query ends (or when ties overfill it).
-// Queries that are not finished after shell r_last hand their state over exactly as the block kernel does; the host
-// continues them in the block kernel (p.slot_list / p.r_first) and then in the multi-block shells.
-// =============================================================================================================
-#define MW_HM 256u                      // hit list entries per wave
-#define MW_HFLUSH 192u
-#ifndef MW_G
-#define MW_G 4u                         // granules per lane per pass
-#endif
-#ifndef MW_EPT
-#define MW_EPT 4u                       // bucket entries per lane per round
-#endif
-#ifndef MW_WAVES
-#define MW_WAVES 3                      // waves per SIMD the kernel is compiled for (3: <= 168 VGPRs, no spills at W <= 2)
-#endif
-#define MW_ROUND (VC_WAVE * MW_EPT)
-#define MW_TAG MQ_TAG
-#define MW_MAXSEG 20u
-
-__device__ __forceinline__ void mw_sync() {   // orders one wave's LDS traffic for the compiler (the hardware keeps it in order)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// per-wave LDS of mih_wave_kernel: candidate buffer | hit list (key, prefix, meta) | 2 distance histograms | masks | segment plan
-static __host__ __device__ inline size_t mw_wave_bytes(uint32_t cb, uint32_t W, uint32_t m) {
-  const size_t b = (size_t)cb * 8 + (size_t)(3 * MW_HM + 1) * 4 + (size_t)2 * mq_hist_bins(W) * 4 +
-                   (size_t)m * (MQ_LO_KNN + 1) * ((1u << MQ_LO_KNN) / 32u) * 4 + (size_t)(4 * MW_MAXSEG + 4) * 4;
-  return (b + 15) & ~(size_t)15;
-}
-static __host__ __device__ inline size_t mw_shared_bytes(uint32_t m) {
-  return (((size_t)m * sizeof(VcTableView) + (size_t)33 * MQ_BW * 4) + 15) & ~(size_t)15;
-}
-
-template <int W>
-__global__ void __launch_bounds__(256, MW_WAVES) mih_wave_kernel(const QueryKernelParams p) {
-  constexpr uint32_t LO = MQ_LO_KNN, HI = 32u - LO, GW = (1u << LO) / 32u, NJ = LO + 1u;
-  static_assert(GW == 4, "one 16-byte load per granule");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
-  const uint32_t m = p.m, CB = p.buf_entries, HB = mq_hist_bins(W);
-  VcTableView* s_tv = (VcTableView*)smem;
-  uint32_t* s_binom = (uint32_t*)(s_tv + m);
-  unsigned char* wb = smem + mw_shared_bytes(m) + (size_t)wave * mw_wave_bytes(CB, W, m);
-  uint64_t* cbuf = (uint64_t*)wb;                    // [CB] candidates (unsorted until the end)
-  uint32_t* hkey = (uint32_t*)(cbuf + CB);           // [MW_HM] bucket key, then entry offset
-  uint32_t* hpref = hkey + MW_HM;                    // [MW_HM + 1] bucket length, then exclusive prefix
-  uint32_t* hmeta = hpref + MW_HM + 1;               // [MW_HM] table | substring distance << 8
-  uint32_t* hist = hmeta + MW_HM;                    // [2][HB]: shells evaluated so far + the pass's first shell | its second shell
-  uint32_t* mask = hist + 2 * HB;                    // [m][NJ][GW]
-  uint32_t* segstart = mask + m * NJ * GW;           // [MW_MAXSEG + 1]
-  uint32_t* segh = segstart + MW_MAXSEG + 1;         // [MW_MAXSEG] |hi| of the segment
-  uint32_t* segj = segh + MW_MAXSEG;                 // [MW_MAXSEG] flips inside the low part (mask index)
-  uint32_t* segr = segj + MW_MAXSEG;                 // [MW_MAXSEG] shell of the segment
-
-  for (uint32_t i = threadIdx.x; i < 33 * MQ_BW; i += blockDim.x) s_binom[i] = c_binom[i / MQ_BW][i % MQ_BW];
-  for (uint32_t i = threadIdx.x; i < m * (sizeof(VcTableView) / 4); i += blockDim.x) ((uint32_t*)s_tv)[i] = ((const uint32_t*)p.tables)[i];
-  __syncthreads();                                   // the only workgroup barrier: the tables above are shared by the four waves
-  const uint32_t slot = blockIdx.x * (blockDim.x / VC_WAVE) + wave;
-  if (slot >= p.nq) return;
-
-  uint64_t qw[W];
-#pragma unroll
-  for (int j = 0; j < W; ++j) qw[j] = p.queries[(uint64_t)slot * W + j];
-  auto qkey = [&](uint32_t t) {
-    const uint32_t bp = t * 32u;
-    uint32_t v = 0;
-#pragma unroll
-    for (int j = 0; j < W; ++j)
-      if ((uint32_t)j == (bp >> 6)) v = (uint32_t)(qw[j] >> (bp & 63));
-    return v;
-  };
-
-  for (uint32_t i = lane; i < 2 * HB; i += VC_WAVE) hist[i] = 0;
-  for (uint32_t i = lane; i < m * NJ * GW; i += VC_WAVE) mask[i] = 0;
-  mw_sync();
-  for (uint32_t i = lane; i < (m << LO); i += VC_WAVE) {   // E_j[t] = { x < 2^LO : popcount(x ^ qlo_t) = j }
-    const uint32_t t = i >> LO, x = i & ((1u << LO) - 1u);
-    const uint32_t j = __popc(x ^ (qkey(t) & ((1u << LO) - 1u)));
-    atomicOr(&mask[(t * NJ + j) * GW + (x >> 5)], 1u << (x & 31));
-  }
-  mw_sync();
-
-  // wave-uniform state
-  uint32_t fill = 0;                       // entries in cbuf
-  uint64_t thr = VC_PACK_INF;              // append iff packed < thr (exclusive bound on what can still be in the top-k)
-  uint32_t seenA = 0, seenB = 0;           // distinct items verified: shells evaluated so far + the pass's first shell | its second shell
-  uint32_t hits0A = 0, hits0B = 0;         // table 0's leaves whose bitmap bit is set (VC_FLAG_USE_BITMAP statistics)
-  uint32_t nh = 0;                         // hit list fill (may exceed MW_HM until drained)
-  uint32_t r_tag = 0xFFFFFFFFu;            // substring distance that marks the second shell of a paired pass
-  unsigned long long sub = 0, loc = 0, w_probes = 0, w_hits = 0, w_entries = 0;
-
-  auto wave_sort = [&](uint32_t P) {       // bitonic network over cbuf[0..P), one wave
-    for (uint32_t size = 2; size <= P; size <<= 1)
-      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-        mw_sync();
-        for (uint32_t i = lane; i < (P >> 1); i += VC_WAVE) {
-          const uint32_t lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
-          const uint64_t x = cbuf[lo], y = cbuf[hi];
-          if ((x > y) == ((lo & size) == 0)) {
-            cbuf[lo] = y;
-            cbuf[hi] = x;
-          }
-        }
-      }
-    mw_sync();
-  };
-  // drop what the threshold has overtaken (and, when asked, the tagged entries); order is not preserved across calls
-  auto compact = [&](bool drop_tagged) {
-    uint32_t nf = 0;
-    for (uint32_t base = 0; base < fill; base += VC_WAVE) {
-      const uint32_t i = base + lane;
-      const uint64_t v = i < fill ? cbuf[i] : VC_PACK_INF;
-      const bool keep = i < fill && (v & ~MW_TAG) < thr && !(drop_tagged && (v & MW_TAG));
-      const uint64_t km = __ballot(keep);
-      mw_sync();                            // every lane has read its entry before any lane overwrites one
-      if (keep) cbuf[nf + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = v;
-      nf += (uint32_t)__popcll(km);
-    }
-    mw_sync();
-    fill = nf;
-  };
-  // exact selection when ties overfill the buffer: sort (tagged entries behind the untagged ones), keep the k best of
-  // either kind -- a superset of the top-k of the first shell alone and of both shells together
-  auto select_exact = [&]() {
-    uint32_t P = 2;
-    while (P < fill) P <<= 1;
-    for (uint32_t i = fill + lane; i < P; i += VC_WAVE) cbuf[i] = VC_PACK_INF;
-    wave_sort(P);
-    uint32_t nU = 0;                        // untagged entries (they sort first)
-    for (uint32_t base = 0; base < fill; base += VC_WAVE) {
-      const uint32_t i = base + lane;
-      nU += (uint32_t)__popcll(__ballot(i < fill && !(cbuf[i] & MW_TAG)));
-    }
-    const uint32_t keepU = min(nU, p.k), keepT = min(fill - nU, p.k);
-    for (uint32_t base = 0; base < keepT; base += VC_WAVE) {   // tagged survivors move up behind the untagged ones
-      const uint32_t i = base + lane;
-      const uint64_t v = i < keepT ? cbuf[nU + i] : 0;
-      mw_sync();
-      if (i < keepT) cbuf[keepU + i] = v;
-    }
-    mw_sync();
-    fill = keepU + keepT;
-    if (nU >= p.k) {                        // k-th best of the first shell(s): an exact bound for everything still to come
-      const uint64_t kv = cbuf[p.k - 1] + 1;
-      const uint64_t kth = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(kv >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)kv);
-      if (kth < thr) thr = kth;
-    }
-  };
-
-  // ---- drain the hit list: entry offsets, prefix sum of the bucket lengths, balanced verify (see mih_query_kernel)
-  auto drain = [&]() {
-    mw_sync();
-    const uint32_t H = min(nh, MW_HM);
-    for (uint32_t i = lane; i < H; i += VC_WAVE) {
-      const uint32_t key = hkey[i];
-      const VcTableView& tv = s_tv[hmeta[i] & 0xFFu];
-      const uint32_t blk = key >> 8, wq = (key >> 5) & 7u;
-      const uint4* bw = reinterpret_cast<const uint4*>(tv.bitmap + ((uint64_t)blk << 3));
-      const uint4 b0 = bw[0], b1 = bw[1];
-      const uint32_t o0 = tv.blockoff[blk], o1 = tv.blockoff[blk + 1];
-      const uint32_t wv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      uint32_t below = 0, all = 0;
-#pragma unroll
-      for (uint32_t j = 0; j < 8; ++j) {
-        all += __popc(wv[j]);
-        below += j < wq ? __popc(wv[j]) : (j == wq ? __popc(wv[j] & ((1u << (key & 31)) - 1u)) : 0u);
-      }
-      uint32_t a, len;
-      if (o1 - o0 == all) {                 // every bucket of the block holds one entry
-        a = o0 + below;
-        len = 1;
-      } else {
-        const uint32_t rk = tv.blockrank[blk] + below;
-        a = tv.offsets[rk];
-        len = tv.offsets[rk + 1] - a;
-      }
-      hkey[i] = a;
-      hpref[i] = len;
-    }
-    mw_sync();
-    uint32_t lsum = 0, lv[MW_HM / VC_WAVE];
-#pragma unroll
-    for (uint32_t i = 0; i < MW_HM / VC_WAVE; ++i) {
-      const uint32_t idx = lane * (MW_HM / VC_WAVE) + i;
-      lv[i] = idx < H ? hpref[idx] : 0;
-      lsum += lv[i];
-    }
-    uint32_t total_v;
-    uint32_t excl = vc_wave_excl_scan(lsum, total_v);
-    const uint32_t total = __builtin_amdgcn_readfirstlane(total_v);
-    mw_sync();
-#pragma unroll
-    for (uint32_t i = 0; i < MW_HM / VC_WAVE; ++i) {
-      const uint32_t idx = lane * (MW_HM / VC_WAVE) + i;
-      if (idx < H) hpref[idx] = excl;
-      excl += lv[i];
-    }
-    if (lane == 0) hpref[H] = total;
-    mw_sync();
-    w_hits += H;
-    w_entries += total;
-
-    for (uint32_t e0 = 0; e0 < total; e0 += MW_ROUND) {
-      if (fill + MW_ROUND > CB) {           // room for one round of survivors
-        compact(false);
-        if (fill + MW_ROUND > CB) select_exact();
-      }
-      uint32_t local[MW_EPT], meta[MW_EPT];
-      uint64_t x[MW_EPT][W];
-      bool live[MW_EPT];
-#pragma unroll
-      for (uint32_t g = 0; g < MW_EPT; ++g) {
-        const uint32_t e = e0 + g * VC_WAVE + lane;
-        live[g] = e < total;
-        const uint32_t ec = live[g] ? e : 0;
-        uint32_t lo = 0, hi = H;            // largest b with hpref[b] <= e
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (hpref[mid] <= ec) lo = mid; else hi = mid;
-        }
-        meta[g] = hmeta[lo];
-        const VcTableView& tv = s_tv[meta[g] & 0xFFu];
-        const uint32_t pos = hkey[lo] + (ec - hpref[lo]);
-        if (W <= 2 && tv.bent) {
-          const uint4 rec = tv.bent[(uint64_t)pos * W];
-          local[g] = rec.x;
-          x[g][0] = ((uint64_t)rec.w << 32) | rec.z;
-          if (W == 2) {
-            const uint4 rec1 = tv.bent[(uint64_t)pos * 2 + 1];
-            x[g][W - 1] = ((uint64_t)rec1.y << 32) | rec1.x;
-          }
-          continue;
-        }
-        local[g] = tv.ids[pos];
-#pragma unroll
-        for (int j = 0; j < W; ++j) x[g][j] = p.cols[(uint64_t)j * p.stride + local[g]];
-      }
-#pragma unroll
-      for (uint32_t g = 0; g < MW_EPT; ++g) {
-        bool emit = live[g];
-        uint64_t packed = 0;
-        uint32_t dist = 0;
-        const uint32_t t = meta[g] & 0xFFu, dt = meta[g] >> 8;
-        if (live[g]) {
-          for (uint32_t tt = 0; tt < m; ++tt) {
-            const uint32_t bp = tt * 32u;
-            uint32_t field = 0;
-#pragma unroll
-            for (int j = 0; j < W; ++j)
-              if ((uint32_t)j == (bp >> 6)) field = (uint32_t)((x[g][j] ^ qw[j]) >> (bp & 63));
-            const uint32_t d = __popc(field);
-            dist += d;
-            // owner rule (mih_probe_kernel): reported by the first table holding the minimum substring distance
-            if (tt != t && (d < dt || (d == dt && tt < t))) emit = false;
-          }
-          packed = vc_pack(dist, p.id_base + local[g]);
-        }
-        const uint64_t emask = __ballot(emit);
-        if (emask == 0) continue;
-        const bool second = dt == r_tag;    // per lane: the entries of one round come from different buckets
-        const uint64_t bmask = __ballot(emit && second);
-        seenB += (uint32_t)__popcll(bmask);
-        seenA += (uint32_t)__popcll(emask & ~bmask);
-        const bool keep = emit && packed < thr;
-        const uint64_t kmask = __ballot(keep);
-        if (kmask == 0) continue;
-        if (keep) {
-          cbuf[fill + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull))] = second ? (packed | MW_TAG) : packed;
-          atomicAdd(&hist[(second ? HB : 0u) + dist], 1u);
-        }
-        fill += (uint32_t)__popcll(kmask);
-      }
-    }
-    mw_sync();
-    nh = 0;
-  };
-
-  // ---- granule scan over the segments of the pass (one or two shells of ALL tables; item = table * per_table + pattern)
-  auto scan = [&]() {
-    const uint32_t nseg = __builtin_amdgcn_readfirstlane(segstart[MW_MAXSEG]);
-    const uint32_t per_table = __builtin_amdgcn_readfirstlane(segstart[nseg]);
-    const uint32_t total = per_table * m;
-    for (uint32_t base = 0; base < total; base += VC_WAVE * MW_G) {
-      const uint32_t idx0 = base + lane * MW_G;
-      uint32_t t = 0, rem = 0, seg = 0, hi = 0;
-      if (idx0 < total) {
-        t = idx0 / per_table;
-        rem = idx0 - t * per_table;
-        while (rem >= segstart[seg + 1]) ++seg;
-        hi = mq_unrank(s_binom, rem - segstart[seg], segh[seg], HI);
-      }
-      uint4 v[MW_G];
-      uint32_t gr[MW_G], meta0[MW_G], mi[MW_G], qlo[MW_G];   // meta0 = table | |hi| << 8 | (second shell of the pass) << 31
-#pragma unroll
-      for (uint32_t g = 0; g < MW_G; ++g) {
-        const uint32_t idx = idx0 + g;
-        gr[g] = 0; meta0[g] = 0; mi[g] = 0; qlo[g] = 0;
-        v[g] = make_uint4(0, 0, 0, 0);
-        if (idx < total) {
-          if (g) {
-            ++rem;
-            if (rem == per_table) {
-              ++t;
-              rem = 0;
-              seg = 0;
-              hi = (1u << segh[0]) - 1u;
-            } else if (rem == segstart[seg + 1]) {
-              ++seg;
-              hi = (1u << segh[seg]) - 1u;
-            } else {
-              hi = vc_next_comb(hi);
-            }
-          }
-          const uint32_t qk = qkey(t);
-          gr[g] = (qk >> LO) ^ hi;
-          qlo[g] = qk & ((1u << LO) - 1u);
-          meta0[g] = t | (segh[seg] << 8) | (segr[seg] == r_tag ? 0x80000000u : 0u);
-          mi[g] = t * NJ + segj[seg];
-          v[g] = *reinterpret_cast<const uint4*>(s_tv[t].bitmap + (uint64_t)gr[g] * GW);
-        }
-      }
-      uint32_t w[MW_G][GW];
-      uint32_t cnt = 0, c0a = 0, c0b = 0;
-#pragma unroll
-      for (uint32_t g = 0; g < MW_G; ++g) {
-        const uint32_t* mk = mask + mi[g] * GW;
-        w[g][0] = v[g].x & mk[0];
-        w[g][1] = v[g].y & mk[1];
-        w[g][2] = v[g].z & mk[2];
-        w[g][3] = v[g].w & mk[3];
-        const uint32_t c = __popc(w[g][0]) + __popc(w[g][1]) + __popc(w[g][2]) + __popc(w[g][3]);
-        cnt += c;
-        if ((meta0[g] & 0xFFu) == 0 && idx0 + g < per_table) {   // table 0's leaves (get_stat of rank 0)
-          if (meta0[g] >> 31) c0b += c; else c0a += c;
-        }
-      }
-      if (p.flags & VC_FLAG_USE_BITMAP) {
-        uint32_t ta, tb;
-        (void)vc_wave_excl_scan(c0a, ta);
-        (void)vc_wave_excl_scan(c0b, tb);
-        hits0A += __builtin_amdgcn_readfirstlane(ta);
-        hits0B += __builtin_amdgcn_readfirstlane(tb);
-      }
-      for (;;) {   // append this pass's hits; what does not fit waits for a drain
-        if (__ballot(cnt != 0) == 0) break;
-        uint32_t wtot_v;
-        uint32_t pos = nh + vc_wave_excl_scan(cnt, wtot_v);
-        const uint32_t wtot = __builtin_amdgcn_readfirstlane(wtot_v);
-#pragma unroll
-        for (uint32_t g = 0; g < MW_G; ++g)
-#pragma unroll
-          for (uint32_t i = 0; i < GW; ++i)
-            while (w[g][i] && pos < MW_HM) {
-              const uint32_t bb = (uint32_t)__ffs((int)w[g][i]) - 1u;
-              w[g][i] &= w[g][i] - 1u;
-              const uint32_t xx = i * 32 + bb;
-              hkey[pos] = (gr[g] << LO) | xx;
-              hmeta[pos] = (meta0[g] & 0xFFFFu) + (__popc(xx ^ qlo[g]) << 8);
-              ++pos;
-              --cnt;
-            }
-        nh += wtot;
-        const uint32_t nh_now = nh;
-        if (nh_now >= MW_HFLUSH) drain();
-        if (nh_now <= MW_HM) break;          // everything fitted
-      }
-    }
-  };
-
-  // segments of a pass over shells r_lo..r_hi: (shell r, |hi| = h, low flips j = r - h <= LO)
-  auto plan = [&](uint32_t r_lo, uint32_t r_hi) {
-    mw_sync();
-    if (lane == 0) {
-      uint32_t ns = 0, start = 0;
-      for (uint32_t r = r_lo; r <= r_hi; ++r)
-        for (uint32_t h = 0; h <= min(r, HI); ++h) {
-          const uint32_t j = r - h;
-          if (j > LO) continue;
-          segstart[ns] = start;
-          segh[ns] = h;
-          segj[ns] = j;
-          segr[ns] = r;
-          start += s_binom[HI * MQ_BW + h];
-          ++ns;
-        }
-      segstart[ns] = start;
-      segstart[MW_MAXSEG] = ns;
-    }
-    mw_sync();
-  };
-
-  auto put_state = [&](uint32_t r) {
-    if (lane == 0) {
-      p.st.work[slot * 4 + 0] = w_probes;
-      p.st.work[slot * 4 + 1] = w_hits;
-      p.st.work[slot * 4 + 2] = w_entries;
-      p.st.radius[slot] = r;
-      p.st.seen[slot] = seenA;
-      p.st.sub[slot] = sub;
-      p.st.loc[slot] = loc;
-    }
-  };
-  // sorted top-k of what the evaluated shells have seen: cbuf[0 .. kk)
-  auto finish_sort = [&]() -> uint32_t {
-    compact(true);
-    uint32_t P = 2;
-    while (P < fill) P <<= 1;
-    for (uint32_t i = fill + lane; i < P; i += VC_WAVE) cbuf[i] = VC_PACK_INF;
-    wave_sort(P);
-    return min(fill, p.k);
-  };
-
-  const uint32_t S = 32;                   // loop bound radius <= n_local_bytes_ * 8 (search_worker.cc:170)
-  for (uint32_t r = 0; r <= p.r_last;) {
-    const uint32_t r_hi = (r == 0 && p.pair01 && p.r_last >= 1) ? 1u : r;
-    r_tag = r_hi != r ? r_hi : 0xFFFFFFFFu;
-    plan(r, r_hi);
-    scan();
-    if (nh) drain();
-    for (uint32_t rr = r; rr <= r_hi; ++rr) {
-      if (rr != r) {                       // second shell of the pass: its candidates join the evaluated set
-        for (uint32_t i = lane; i < HB; i += VC_WAVE) {
-          hist[i] += hist[HB + i];
-          hist[HB + i] = 0;
-        }
-        for (uint32_t i = lane; i < fill; i += VC_WAVE) cbuf[i] &= ~MW_TAG;
-        mw_sync();
-        seenA += seenB;
-        seenB = 0;
-        hits0A = hits0B;
-        hits0B = 0;
-        r_tag = 0xFFFFFFFFu;
-      }
-      const unsigned long long leaves = c_binom[S][rr];
-      w_probes += leaves * m;
-      if (p.flags & VC_FLAG_USE_BITMAP) {
-        loc += leaves;
-        sub += hits0A;
-      } else {
-        sub += leaves;
-      }
-      hits0A = 0;
-      mw_sync();
-      const uint32_t dk = seenA >= p.k ? __builtin_amdgcn_readfirstlane(mw_hist_cut(hist, W * 64u + 1u, p.k)) : 0xFFFFFFFFu;
-      bool stop;
-      if (p.mode == MQ_MODE_APPROX)        // search_worker.cc:136-137: the heap of k*20 distinct candidates is full
-        stop = seenA >= p.k * MIH_APPROX_FACTOR;
-      else                                 // search_worker.cc:201-205: size == k && top.dist <= radius * 4 (radius already incremented)
-        stop = dk != 0xFFFFFFFFu && dk <= (rr + 1) * p.stop_mult;
-      if (stop || rr == S) {
-        const uint32_t kk = finish_sort();
-        for (uint32_t i = lane; i < p.k; i += VC_WAVE) p.out[(uint64_t)slot * p.k + i] = i < kk ? cbuf[i] : VC_PACK_INF;
-        if (lane == 0) p.out_cnt[slot] = kk;
-        put_state(rr);
-        return;
-      }
-      if (dk != 0xFFFFFFFFu) {             // everything farther than the k-th distance is out for good
-        const uint64_t b = ((uint64_t)dk + 1) << 32;
-        if (b < thr) thr = b;
-      }
-    }
-    r = r_hi + 1;
-  }
-  // not finished: hand the query over (state exactly as mih_commit_kernel / mih_query_kernel leave it)
-  const uint32_t kk = finish_sort();
-  for (uint32_t i = lane; i < kk; i += VC_WAVE) p.st.topk[(uint64_t)slot * p.k + i] = cbuf[i];
-  put_state(0);
-  if (lane == 0) {
-    p.st.count[slot] = kk;
-    p.st.prev[slot] = kk;
-    p.st.thresh[slot] = kk == p.k ? cbuf[p.k - 1] : VC_PACK_INF;
-    p.st.topn[slot] = kk;
-    p.heavy_list[atomicAdd(p.heavy_ctr, 1u)] = slot;
-  }
-}
-
 
 // =============================================================================================================
 // mih_bucket_stream_kernel -- fixed-radius search over <= 16-bit substrings (BASELINE configs[1], m = 4 x 16 bit):
@@ -2180,15 +1728,12 @@ __global__ void __launch_bounds__(256) mih_minsub_count_kernel(const uint64_t* _
 
 // sum the per-query work counters of one mih_query_kernel launch into the index-wide totals (vc_get_timing)
 __global__ void __launch_bounds__(256) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
-                                                              unsigned long long* __restrict__ totals, const uint32_t* __restrict__ list,
-                                                              uint32_t count_queries, const uint32_t* __restrict__ list_count) {
-  if (list_count) nq = min(nq, *list_count);
+                                                              unsigned long long* __restrict__ totals) {
   __shared__ unsigned long long s_t[3];
   if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long a = 0, b = 0, c = 0;
-  for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) {
-    const uint32_t i = list ? list[j] : j;
+  for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
     a += work[i * 4 + 0];
     b += work[i * 4 + 1];
     c += work[i * 4 + 2];
@@ -2198,7 +1743,7 @@ __global__ void __launch_bounds__(256) mih_work_reduce_kernel(const unsigned lon
   atomicAdd(&s_t[2], c);
   __syncthreads();
   if (threadIdx.x < 3) totals[threadIdx.x] += s_t[threadIdx.x];
-  if (threadIdx.x == 3 && count_queries) totals[3] += nq;
+  if (threadIdx.x == 3) totals[3] += nq;
 }
 
 // per-query result segments of the radius search: ring[q][0 .. min(count, cap)) sorted ascending in place.
@@ -2334,6 +1879,7 @@ struct VcMihIndex {
   uint64_t* d_ring = nullptr;               // [MIH_QTILE][cap] candidate rings of the multi-block shells (lazy)
   size_t ring_entries = 0;
   size_t lds_per_block = 65536;             // hipDeviceProp.sharedMemPerBlock of the index's device
+  uint32_t group_hint = 2;                  // shells grouped into the query kernel's first pass (adapts to where queries stop)
 };
 
 #define MIH_CHECK(call)                                                                                  \
@@ -2491,8 +2037,8 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
       hipLaunchKernelGGL(mih_ranked_offsets_kernel, dim3(grid_for(nn, n_cu)), dim3(256), 0, s, k_out, n, bitmap, blockrank,
                          offsets, tv.n_unique);
       B_CHECK(hipGetLastError());
-      uint32_t* blockoff = nullptr;
-      B_CHECK(dalloc((void**)&blockoff, ((size_t)nblocks + 1) * 4, true));
+      uint2* blockoff = nullptr;
+      B_CHECK(dalloc((void**)&blockoff, ((size_t)nblocks + 1) * 8, true));
       hipLaunchKernelGGL(mih_blockoff_kernel, dim3(n_cu * 16), dim3(256), 0, s, blockrank, offsets, nblocks, tv.n_unique, blockoff);
       B_CHECK(hipGetLastError());
       tv.blockoff = blockoff;
@@ -2849,8 +2395,8 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
       }
     }
     if (sbits == 32) {   // derived directory, not in the file (see VcTableView::blockoff)
-      uint32_t* blockoff = nullptr;
-      if ((rc = dalloc((void**)&blockoff, ((size_t)(1u << 24) + 1) * 4))) break;
+      uint2* blockoff = nullptr;
+      if ((rc = dalloc((void**)&blockoff, ((size_t)(1u << 24) + 1) * 8))) break;
       hipLaunchKernelGGL(mih_blockoff_kernel, dim3(n_cu * 16), dim3(256), 0, s, blockrank, offsets, 1u << 24, tv.n_unique, blockoff);
       tv.blockoff = blockoff;
     }
@@ -2910,7 +2456,7 @@ static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, bool with_ring,
     MIH_CHECK(hipMalloc((void**)&ix->d_ring, Q * cap * 8));
     ix->ring_entries = Q * cap;
   }
-  if (!ix->d_lists) MIH_CHECK(hipMalloc((void**)&ix->d_lists, (4 * Q + 4) * 4));
+  if (!ix->d_lists) MIH_CHECK(hipMalloc((void**)&ix->d_lists, (4 * Q + 8) * 4));   // 4 slot lists + 4 counters + 4 stop-shell counts
   uint8_t* b = (uint8_t*)ix->d_tile;
   st->thresh = (uint64_t*)(b + o_thresh);
   st->ring = ix->d_ring;
@@ -2941,7 +2487,8 @@ static hipError_t launch_probe(const ProbeParams& p, uint32_t W, uint32_t n_list
 static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits, uint32_t W = VC_MAX_W) {
   return (size_t)buf_entries * 8 + (size_t)(3 * MQ_HMAX + 1) * 4 + (size_t)33 * MQ_BW * 4 +
          (sbits == 32 ? (size_t)m * (MQ_LO_MAX + 1) * ((1u << MQ_LO_MAX) / 32u) * 4 : 0) +   // masks sized for the widest granule
-         (size_t)2 * mq_hist_bins(W) * 4 + 16;                                                  // k-NN distance histograms
+         (size_t)MQ_MAX_GROUP * mq_hist_bins(W) * 4 + 16 +                                      // k-NN distance histograms, one per shell class
+         (size_t)m * sizeof(VcTableView) + 16;                                                   // the tables' views
 }
 
 static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s) {
@@ -2962,22 +2509,15 @@ static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, ui
   return hipGetLastError();
 }
 
-static hipError_t launch_wave_kernel(const QueryKernelParams& p, uint32_t W, hipStream_t s) {
-  const size_t lds = mw_shared_bytes(p.m) + (size_t)(MQ_BLK / VC_WAVE) * mw_wave_bytes(p.buf_entries, W, p.m);
-  const dim3 grid((p.nq + MQ_BLK / VC_WAVE - 1) / (MQ_BLK / VC_WAVE));
-  switch (W) {
-    case 1: hipLaunchKernelGGL(mih_wave_kernel<1>, grid, dim3(MQ_BLK), lds, s, p); break;
-    case 2: hipLaunchKernelGGL(mih_wave_kernel<2>, grid, dim3(MQ_BLK), lds, s, p); break;
-    case 4: hipLaunchKernelGGL(mih_wave_kernel<4>, grid, dim3(MQ_BLK), lds, s, p); break;
-    case 8: hipLaunchKernelGGL(mih_wave_kernel<8>, grid, dim3(MQ_BLK), lds, s, p); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
 // launch + measurement: events on the launch stream around the kernel, then the reduction of its work counters
-// (wave = mih_wave_kernel over p.nq queries; otherwise mih_query_kernel over nq blocks, p.slot_list naming their slots)
-static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s, bool wave = false) {
+static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_in, uint32_t W, uint32_t nq, hipStream_t s) {
+  QueryKernelParams p = p_in;
+  static unsigned long long* d_phase = nullptr;   // dev knob VC_MIH_PHASES: one buffer per process is enough
+  if (ix->knobs.mih_phases && p.mode != MQ_MODE_RADIUS) {
+    if (!d_phase && hipMalloc((void**)&d_phase, 64) != hipSuccess) d_phase = nullptr;
+    if (d_phase) (void)hipMemsetAsync(d_phase, 0, 64, s);
+    p.phase_dbg = d_phase;
+  }
   if (!ix->d_totals) {
     hipError_t r = hipMalloc((void**)&ix->d_totals, 32);
     if (r == hipSuccess) r = hipMemsetAsync(ix->d_totals, 0, 32, s);
@@ -2994,12 +2534,16 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p,
     if (ix->ev_used < ix->ev_pool.size()) ev = &ix->ev_pool[ix->ev_used++];
   }
   if (ev) (void)hipEventRecord(ev->first, s);
-  hipError_t r = wave ? launch_wave_kernel(p, W, s) : launch_query_kernel(p, W, nq, s);
+  hipError_t r = launch_query_kernel(p, W, nq, s);
   if (ev) (void)hipEventRecord(ev->second, s);
   if (r != hipSuccess) return r;
-  // a continuation launch (slot_list) adds its own work to the totals but its queries were counted by the first launch
-  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(256), 0, s, p.st.work, nq, ix->d_totals, p.slot_list, p.slot_list ? 0u : 1u,
-                     p.slot_count);
+  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(256), 0, s, p.st.work, nq, ix->d_totals);
+  if (p.phase_dbg) {
+    unsigned long long h[8];
+    if (hipMemcpyAsync(h, p.phase_dbg, 64, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
+      fprintf(stderr, "[vc_mih phases] %u blocks, us per block: setup+scan %.1f | directory %.1f | verify %.1f | evaluate %.1f | finish %.1f | out %.1f\n", nq,
+              h[1] * 0.01 / nq, h[2] * 0.01 / nq, h[3] * 0.01 / nq, h[4] * 0.01 / nq, h[5] * 0.01 / nq, h[6] * 0.01 / nq);
+  }
   return hipGetLastError();
 }
 
@@ -3099,13 +2643,13 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   // stop multiplier: the reference's literal 4 (search_worker.cc:204); min(m,4) keeps m < 4 exact
   const uint32_t stop_mult = (ix->flags & VC_FLAG_REF_STOP_LITERAL4) ? 4u : std::min(ix->m, 4u);
   MihState st;
-  if (!ix->h_ctr) MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 16, hipHostMallocDefault));   // pageable memory makes the read-back a staged copy
+  if (!ix->h_ctr) MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 32, hipHostMallocDefault));   // pageable memory makes the read-back a staged copy
   uint32_t* h_ctr = ix->h_ctr;
 
   // Shells 0..r_last run inside ONE launch, one block per query (mih_query_kernel); the host reads ONE counter per
   // tile (how many queries are not finished) and only those continue shell by shell through the multi-block kernels.
-  uint32_t buf_entries = 1024;     // candidates of one block: up to k of either shell of a paired pass + one round of survivors
-  while (buf_entries < 2 * k + MQ_ROUND) buf_entries <<= 1;
+  uint32_t buf_entries = 1024;     // candidates of one block: up to k of every shell class of a grouped pass + one round of survivors
+  while (buf_entries < MQ_MAX_GROUP * k + MQ_ROUND) buf_entries <<= 1;
   // the query kernel's LDS request (top-k + candidate buffer, hit lists, binomials, masks) must fit a workgroup of this
   // device (k = 3073..7168 asks for ~82 KB); otherwise every shell runs through the multi-block kernels
   const bool inblock = ix->knobs.mih_host_loop == 0 && buf_entries <= 8192 && ix->m <= 64 &&
@@ -3125,15 +2669,13 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   // the scan switch reproduces the radius loop only where that loop is exact and its counters have a closed form
   const bool switch_ok = !approximate && ix->knobs.mih_switch != 0 && !(ix->flags & (VC_FLAG_USE_BITMAP | VC_FLAG_REF_SIGNEXT_KEYS)) &&
                          stop_mult == std::min(ix->m, 4u) && n >= 1;
-  // mih_wave_kernel: 32-bit substrings, k small enough for a per-wave candidate buffer of 2k + one round of survivors
-  uint32_t wave_cb = 512;
-  while (wave_cb < 2 * k + MW_ROUND) wave_cb <<= 1;
-  // the wave stage runs the cheap shells only (0 and 1: 27 granules per table, one pass): a launch lasts as long as its
-  // slowest wave, and a wave that walks the 2 600 granules per table of shell 3 alone takes ~0.4 ms (measured: shells 0..3
-  // in the wave stage 7.3 M queries/s, 0..2 8.7 M, against 10.1 M for the block kernel alone)
-  uint32_t r_wave = std::min(r_last, ix->knobs.mih_wave_shells >= 0 ? (uint32_t)ix->knobs.mih_wave_shells : 1u);
-  const bool wave_ok = inblock && S == 32 && ix->knobs.mih_wave != 0 && wave_cb <= 1024 && ix->m <= 16 &&
-                       mw_shared_bytes(ix->m) + (size_t)(MQ_BLK / VC_WAVE) * mw_wave_bytes(wave_cb, ix->W, ix->m) <= ix->lds_per_block;
+  // Shells that share the FIRST pass of the query kernel (32-bit substrings): their candidates are tagged by shell and the
+  // stop rule is evaluated shell by shell afterwards, so grouping changes no result and no statistic -- it saves a scan /
+  // drain round per grouped shell and wastes the probes of the shells behind the one a query stops in.  The depth follows
+  // the workload: the kernel counts where the queries of a launch stopped, and the next launch groups up to the shell
+  // most of them needed (at most 3; VC_MIH_GROUP fixes it).
+  uint32_t group = ix->knobs.mih_group > 0 ? (uint32_t)ix->knobs.mih_group : ix->group_hint;
+  group = std::max(1u, std::min(group, std::min(3u, r_last + 1)));
 
   for (uint32_t q0 = 0; q0 < nq; q0 += MIH_QTILE) {
     const uint32_t qt = std::min(MIH_QTILE, nq - q0);
@@ -3145,36 +2687,15 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       qp.st = st; qp.m = ix->m; qp.sbits = S; qp.id_base = ix->id_base; qp.flags = ix->flags; qp.cap = cap; qp.k = k;
       qp.mode = approximate ? MQ_MODE_APPROX : MQ_MODE_EXACT; qp.stop_mult = stop_mult; qp.r_last = r_last;
       qp.buf_entries = buf_entries; qp.heavy_list = cur; qp.heavy_ctr = d_ctr + 2;
-      qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0; qp.pair01 = ix->knobs.mih_pair01 ? 1u : 0u;
+      qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0; qp.group = group; qp.radius_hist = d_ctr + 4;
       const auto t_q = std::chrono::steady_clock::now();
-      MIH_CHECK(hipMemsetAsync(d_ctr, 0, 16, s));
-      if (wave_ok) {
-        // stage 1: one wave per query, shells 0..r_wave (mih_wave_kernel); stage 2: the unfinished queries continue in
-        // the block-per-query kernel (256 threads spread a big shell), shells r_wave + 1 .. r_last
-        QueryKernelParams wp = qp;
-        wp.buf_entries = wave_cb; wp.r_last = r_wave; wp.nq = qt; wp.pair01 = ix->knobs.mih_pair01 ? 1u : 0u;
-        MIH_CHECK(timed_query_launch(ix, wp, ix->W, qt, s, true));
-        if (r_wave < r_last) {
-          // launched for every query of the tile right behind stage 1; the blocks beyond the device-side count of
-          // unfinished queries leave at once -- no host round trip between the stages
-          qp.slot_list = cur; qp.slot_count = d_ctr + 2; qp.r_first = r_wave + 1; qp.heavy_list = nxt; qp.heavy_ctr = d_ctr + 3;
-          MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
-          MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 8, hipMemcpyDeviceToHost, s));
-          MIH_CHECK(hipStreamSynchronize(s));
-          if (trace) fprintf(stderr, "[vc_mih] one wave per query, shells 0..%u: %u of %u queries continue in the block kernel\n", r_wave, h_ctr[2], qt);
-          n_heavy = n_cur = h_ctr[3];
-          std::swap(cur, nxt);
-        } else {
-          MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 4, hipMemcpyDeviceToHost, s));
-          MIH_CHECK(hipStreamSynchronize(s));
-          n_heavy = n_cur = h_ctr[2];
-        }
-      } else {
-        MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
-        MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 4, hipMemcpyDeviceToHost, s));
-        MIH_CHECK(hipStreamSynchronize(s));
-        n_heavy = n_cur = h_ctr[2];
-      }
+      MIH_CHECK(hipMemsetAsync(d_ctr, 0, 32, s));
+      MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
+      MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 24, hipMemcpyDeviceToHost, s));   // unfinished queries + where the others stopped
+      MIH_CHECK(hipStreamSynchronize(s));
+      n_heavy = n_cur = h_ctr[2];
+      if (S == 32 && qt >= 64)       // next launch: group up to shell 2 when most queries of this one needed it
+        ix->group_hint = (uint64_t)(h_ctr[6] + h_ctr[7]) * 10 >= (uint64_t)qt * 6 ? 3u : 2u;
       r_start = r_last + 1;
       if (trace)
         fprintf(stderr, "[vc_mih] shells 0..%u in the query kernels: %u queries, %u continue  %.1f us\n", r_last, qt, n_cur,
