@@ -165,11 +165,28 @@ def linear_knn(codes, query, k, id_base=0, threads=1):
 
 # ------------------------------------------------------------------ big databases: a persistent worker pool
 def host_threads():
-    """threads this process may really use (the GPU box reports 256 cores but a job owns a share of them)"""
+    """threads this process may really use: the affinity mask, capped by the cgroup's CPU quota (the GPU box reports 256
+    cores and an affinity mask of 256, but a one-GPU job's cpu.max is 16 CPUs: 256 threads would share 16 cores' time)"""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], int(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    period = int(g.read())
+            if quota not in ("max", "-1") and int(quota) > 0:
+                n = min(n, max(1, int(quota) // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 class Pool:

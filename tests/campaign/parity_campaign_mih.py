@@ -81,6 +81,16 @@ def main():
         mo = oracle.MihOracle(codes, m, key_mode=0 if signext else 1, id_base=id_base)
         desc = "bits=%3d s=%2d n=%7d centres=%4d flips=%2d k=%3d nq=%2d flag=%-8s approx=%d" % (
             bits, s, n, centres, flips, k, nq, flag, approx)
+        # every fifth case sends the exact loop through the verify kernel + replayed stop rule (the cost-model switch, forced),
+        # another fifth sends <= 16-bit radius searches through the bucket streaming kernel (knobs are read at vc_create)
+        for kn in ("VC_MIH_SWITCH", "VC_MIH_HOST_LOOP", "VC_MIH_STREAM"):
+            os.environ.pop(kn, None)
+        if i % 5 == 3:
+            os.environ.update(VC_MIH_SWITCH="2", VC_MIH_HOST_LOOP="1")
+            desc += " [switch]"
+        elif i % 5 == 4:
+            os.environ["VC_MIH_STREAM"] = "2"
+            desc += " [stream]"
         with vc.Engine(bits, capacity=n, n_tables=m, flags=flags, id_base=id_base,
                        query_tile=int(rng.choice([1, 4, 32]))) as e:
             if i % 2:

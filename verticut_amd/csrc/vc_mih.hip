@@ -785,6 +785,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   const uint32_t s = p.sbits, m = p.m;
   const uint32_t smask = s == 32 ? 0xFFFFFFFFu : ((1u << s) - 1u);
   const bool knn = p.mode != MQ_MODE_RADIUS;
+  const unsigned long long t_entry = p.phase_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   uint64_t qw[W];
 #pragma unroll
@@ -849,7 +850,11 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       s_ph_cur = next;
     }
   };
-  if (p.phase_dbg && tid == 0) { s_ph_last = __builtin_amdgcn_s_memrealtime(); s_ph_cur = 1; }
+  if (p.phase_dbg && tid == 0) {
+    s_ph_last = __builtin_amdgcn_s_memrealtime();
+    s_ph_cur = 0;
+    atomicAdd(&p.phase_dbg[7], s_ph_last - t_entry);   // set-up: query, tables, binomials, masks
+  }
   uint32_t r_base = 0;             // first shell of the current pass: a candidate's class = its substring distance - r_base (block-uniform)
   uint32_t kk = 0;                 // radius mode: sorted results in s_buf[0..kk)           (block-uniform)
   bool spilled = false;            // radius mode: results went to the global ring unsorted (block-uniform)
@@ -1287,6 +1292,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     __syncthreads();
   };
 
+  tick(1);                         // (phase 0 = set-up: tables, binomials, masks -- but the phase clock starts after them)
   const uint32_t S = s;            // loop bound radius <= n_local_bytes_ * 8 (search_worker.cc:170)
   if (!knn) {
     // fixed-radius neighbour search, every item within the full distance R kept.  Pigeonhole with the sharper radii of
@@ -1434,6 +1440,12 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     p.st.topn[slot] = kout;
     p.heavy_list[atomicAdd(p.heavy_ctr, 1u)] = slot;
     if (p.radius_hist) atomicAdd(&p.radius_hist[3], 1u);
+    // what the radius loop may still cost this query: the k-th distance so far bounds the true one from above, so the loop
+    // ends by shell floor(D_bound / mult) at the latest (search_worker.cc:201-205); all shells when k items are not found yet
+    const uint32_t r_end = kout == p.k ? min(S, (uint32_t)(s_buf[p.k - 1] >> 32) / max(p.stop_mult, 1u)) : S;
+    unsigned long long pred = 0;
+    for (uint32_t r = p.r_last + 1; r <= r_end; ++r) pred += (unsigned long long)m * c_binom[s][r];
+    p.st.work[slot * 4 + 3] = pred;
   }
 }
 
@@ -1596,6 +1608,18 @@ __global__ void __launch_bounds__(256) mih_gather_queries_kernel(const uint64_t*
                                                                  uint32_t n, uint32_t W, uint64_t* __restrict__ out) {
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n * W; e += gridDim.x * blockDim.x)
     out[e] = q[(uint64_t)list[e / W] * W + e % W];
+}
+
+// heavy queries after the in-kernel shells: those whose predicted remaining probes (work[slot][3], written at hand-over)
+// exceed `limit` go to list_a (answered by the verify kernel), the others to list_b (radius loop continues)
+__global__ void __launch_bounds__(256) mih_partition_kernel(const uint32_t* __restrict__ list, uint32_t n,
+                                                            const unsigned long long* __restrict__ work, unsigned long long limit,
+                                                            uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, uint32_t* __restrict__ ctr) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t slot = list[i];
+  if (work[slot * 4 + 3] > limit) list_a[atomicAdd(&ctr[0], 1u)] = slot;
+  else list_b[atomicAdd(&ctr[1], 1u)] = slot;
 }
 
 #define MR_TIES 8192u
@@ -2541,8 +2565,8 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
   if (p.phase_dbg) {
     unsigned long long h[8];
     if (hipMemcpyAsync(h, p.phase_dbg, 64, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
-      fprintf(stderr, "[vc_mih phases] %u blocks, us per block: setup+scan %.1f | directory %.1f | verify %.1f | evaluate %.1f | finish %.1f | out %.1f\n", nq,
-              h[1] * 0.01 / nq, h[2] * 0.01 / nq, h[3] * 0.01 / nq, h[4] * 0.01 / nq, h[5] * 0.01 / nq, h[6] * 0.01 / nq);
+      fprintf(stderr, "[vc_mih phases] %u blocks, us per block: set-up %.1f | plan+scan %.1f | directory %.1f | verify %.1f | evaluate %.1f | finish %.1f | out %.1f\n", nq,
+              (h[7] + h[0]) * 0.01 / nq, h[1] * 0.01 / nq, h[2] * 0.01 / nq, h[3] * 0.01 / nq, h[4] * 0.01 / nq, h[5] * 0.01 / nq, h[6] * 0.01 / nq);
   }
   return hipGetLastError();
 }
@@ -2705,6 +2729,36 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
         if ((rc = ensure_tile(ix, k, cap, true, &st, err))) return rc;   // the rings exist from the first hand-over on
         hipLaunchKernelGGL(mih_seed_ring_kernel, dim3(n_heavy), dim3(256), 0, s, st, (const uint32_t*)cur, k, cap);
         MIH_CHECK(hipGetLastError());
+        if (fb && fb->fn && switch_ok) {
+          // Cost model, per query: the hand-over left an upper bound of the probes each query may still need (its k-th
+          // distance so far bounds its last shell).  The multi-block kernels sustain ~4e10 probes/s; a verify pass streams the
+          // shard once per 8 queries at ~6 TB/s (x 2.5 with the statistics pass).  Queries beyond the break-even are answered
+          // by the scan NOW, stop rule replayed (mih_replay_kernel) -- the others keep their radius loop.
+          const double pass_s = (double)n * ix->W * 8 / 6e12 + 40e-6;
+          const double limit = ix->knobs.mih_switch == 2 ? -1.0 : pass_s / 8 * (stats ? 2.5 : 1.0) * 4e10;
+          MIH_CHECK(hipMemsetAsync(d_ctr, 0, 8, s));
+          hipLaunchKernelGGL(mih_partition_kernel, dim3((n_heavy + 255) / 256), dim3(256), 0, s, (const uint32_t*)cur, n_heavy, st.work,
+                             limit < 0 ? 0ull : (unsigned long long)limit, nxt, redo, d_ctr);
+          MIH_CHECK(hipGetLastError());
+          MIH_CHECK(hipMemcpyAsync(h_ctr, d_ctr, 8, hipMemcpyDeviceToHost, s));
+          MIH_CHECK(hipStreamSynchronize(s));
+          const uint32_t n_scan = h_ctr[0], n_keep = h_ctr[1];
+          if (n_scan) {
+            VcMihScanTarget tgt{st.ring, cap, st.count, st.radius, st.seen, st.sub, st.loc};
+            MIH_CHECK(hipMemsetAsync(d_ctr, 0, 4, s));
+            // unresolved queries (ring overflow, too many ties) rejoin the radius loop: appended behind the kept ones
+            rc = fb->fn(fb->ctx, d_q + (size_t)q0 * ix->W, nxt, n_scan, k, stop_mult, tgt, stats != nullptr, redo + n_keep, d_ctr, s);
+            if (rc) {
+              if (err) *err = "scan fallback of the exact k-NN loop failed";
+              return rc;
+            }
+            MIH_CHECK(hipMemcpyAsync(h_ctr, d_ctr, 4, hipMemcpyDeviceToHost, s));
+            MIH_CHECK(hipStreamSynchronize(s));
+            if (trace) fprintf(stderr, "[vc_mih] cost model: %u of %u unfinished queries answered by the verify kernel, %u came back\n", n_scan, n_heavy, h_ctr[0]);
+            n_cur = n_keep + h_ctr[0];
+            std::swap(cur, redo);          // the radius loop goes on with the kept (+ unresolved) queries
+          }
+        }
       }
     } else {
       hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, cur, (uint64_t)VC_PACK_INF);
