@@ -11,7 +11,7 @@ struct VcKnobs {
   uint64_t sample1 = 0;
   bool shape_set = false;                     // VC_SCAN_SHAPE "U,BLK,DB"
   int shape_u = 0, shape_blk = 0, shape_db = 0;
-  uint32_t sample_blocks_per_cu = 8;          // VC_SAMPLE_BLOCKS_PER_CU
+  uint32_t sample_blocks_per_cu = 4;          // VC_SAMPLE_BLOCKS_PER_CU (8 -> 4 in round 3: -1.5..6 us per 125 M-code step, two A/B pairs)
   bool recover_trace = false;                 // VC_RECOVER_TRACE
   bool mih_trace = false;                     // VC_MIH_TRACE
   bool device_recover = true;                 // VC_DEVICE_RECOVER=0: ring overflow handled by the host-driven fallback only

@@ -76,15 +76,33 @@ __global__ void __launch_bounds__(256) mih_bcodes_kernel(const uint64_t* __restr
 
 __global__ void __launch_bounds__(256) mih_bent_kernel(const uint64_t* __restrict__ cols, uint64_t stride, uint32_t W,
                                                        const uint32_t* __restrict__ ids, uint64_t n, uint4* __restrict__ out) {
-  for (uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t id = ids[pos];
-    const uint64_t c0 = cols[id];
-    if (W == 1) {
-      out[pos] = make_uint4(id, 0u, (uint32_t)c0, (uint32_t)(c0 >> 32));
-    } else {   // W == 2: 32 bytes per entry, half a sector
-      const uint64_t c1 = cols[stride + id];
-      out[2 * pos] = make_uint4(id, 0u, (uint32_t)c0, (uint32_t)(c0 >> 32));
-      out[2 * pos + 1] = make_uint4((uint32_t)c1, (uint32_t)(c1 >> 32), 0u, 0u);
+  // a permutation gather: 8 entries per thread in flight (ids first, then their code words), or the 1e9-entry tables of
+  // the metric's size take a second each -- one dependent pair of round trips per entry and thread otherwise
+  constexpr int U = 8;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t p0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < n; p0 += step * U) {
+    uint32_t id[U];
+    uint64_t c0[U], c1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t pos = p0 + u * step;
+      id[u] = pos < n ? __builtin_nontemporal_load(ids + pos) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      c0[u] = cols[id[u]];
+      c1[u] = W == 2 ? cols[stride + id[u]] : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t pos = p0 + u * step;
+      if (pos >= n) continue;
+      if (W == 1) {
+        out[pos] = make_uint4(id[u], 0u, (uint32_t)c0[u], (uint32_t)(c0[u] >> 32));
+      } else {   // W == 2: 32 bytes per entry, half a sector
+        out[2 * pos] = make_uint4(id[u], 0u, (uint32_t)c0[u], (uint32_t)(c0[u] >> 32));
+        out[2 * pos + 1] = make_uint4((uint32_t)c1[u], (uint32_t)(c1[u] >> 32), 0u, 0u);
+      }
     }
   }
 }
@@ -1984,7 +2002,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
   bool want_bent = sbits == 32 && W <= 2;   // (VcTableView::bent; VC_MIH_BENT=0/1 overrides)
   {
     size_t free_b = 0, total_b = 0;
-    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 * W > free_b / 3) want_bent = false;
+    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 * W > free_b / 100 * 55) want_bent = false;   // (55 % of the free memory: 128 GB of records at 1e9 x 128 bit next to 50 GB of codes + index on a 288 GB part)
     if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W <= 2;
   }
   const uint64_t nkeyspace = 1ull << sbits;
@@ -2335,7 +2353,7 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
   bool want_bent = sbits == 32 && W <= 2;
   {
     size_t free_b = 0, total_b = 0;
-    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 * W > free_b / 3) want_bent = false;
+    if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 * W > free_b / 100 * 55) want_bent = false;   // (55 % of the free memory: 128 GB of records at 1e9 x 128 bit next to 50 GB of codes + index on a 288 GB part)
     if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W <= 2;
   }
   auto dalloc = [&](void** p, size_t bytes) -> int {
