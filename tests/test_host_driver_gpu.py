@@ -51,6 +51,12 @@ def test_driver_file_queries_match_oracle(vc, oracle, tmp_path):
         sub_sum += ost.n_sub_reads
     avg = re.search(r"n_sub_reads : (\d+), n_local_reads : (\d+), radius : (\d+), rdma", out.split("Averate result")[1])
     assert (int(avg.group(1)), int(avg.group(3))) == (sub_sum // len(q), rad_sum // len(q))
+    # the driver searches the file's queries in ONE batched call (SearchWorker::find_batch); the reference's one-find-per-
+    # query sequence prints the same lines
+    one = _run([tmp_path / "lsh.code", n, bits, bits // m, k, "pilaf", 0, 0, -1, tmp_path / "query.code"],
+               {"VC_PRINT_RESULTS": "1", "VC_QUERY_BY_QUERY": "1"})
+    strip = lambda t: [ln for ln in t.splitlines() if not ln.startswith("while :")]
+    assert strip(one) == strip(out)
 
 
 def test_driver_query_by_id(vc, oracle, tmp_path):

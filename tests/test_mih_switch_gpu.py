@@ -36,8 +36,8 @@ def test_forced_switch_reproduces_the_radius_loop(vc, oracle, monkeypatch, bits,
     rng = np.random.default_rng(bits * 7 + m + k)
     codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=60, max_flips=2 * m)
     # far queries: uniform random ones where the ORACLE's shell enumeration stays cheap (<= 16-bit substrings: at most 2^16
-    # keys per table), else database items with up to 6 m flips (k-th distance up to ~25: shells 0..6 of 32-bit substrings)
-    far = (rng.integers(0, 256, size=(4, bits // 8), dtype=np.uint8) if bits // m <= 16 else _near(codes, rng, 4, 6 * m))
+    # keys per table), else database items with up to 24 flips (k-th distance up to ~25: shells 0..6 of 32-bit substrings)
+    far = (rng.integers(0, 256, size=(4, bits // 8), dtype=np.uint8) if bits // m <= 16 else _near(codes, rng, 4, min(6 * m, 24)))
     q = np.concatenate([_near(codes, rng, 20, m + 2), far])
     mo = oracle.MihOracle(codes, m, key_mode=1)
     s = bits // m

@@ -98,23 +98,41 @@ int main(int argc, char** argv) {
     }
     uint64_t n_main_total = 0, n_sub_total = 0, n_local_total = 0, radius_total = 0;
     int n_query = 0;
+    // distributed_image_search.cc:62-85 searches the file's queries one by one (at most 200, :83-84); here they are read
+    // first and searched in ONE batched call -- same results, same statistics, same output lines (VC_QUERY_BY_QUERY=1
+    // keeps the reference's one-find-per-query sequence, e.g. to time single-query latency)
+    std::vector<char> qbuf;
     std::vector<char> code(nbytes);
+    while (n_query < 200 && fread(code.data(), nbytes, 1, f) != 0) {
+      qbuf.insert(qbuf.end(), code.begin(), code.end());
+      n_query++;
+    }
+    const bool one_by_one = getenv("VC_QUERY_BY_QUERY") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    while (fread(code.data(), nbytes, 1, f) != 0) {   // distributed_image_search.cc:62-85
-      std::list<vc::SearchWorker::search_result_st> result = worker.find(code.data(), nbytes, k, approximate);
-      worker.get_stat(n_main_reads, n_sub_reads, n_local_reads, radius);
+    std::vector<std::list<vc::SearchWorker::search_result_st> > results;
+    std::vector<vc_query_stats> stats;
+    if (one_by_one) {
+      for (int q = 0; q < n_query; ++q) {
+        results.push_back(worker.find(qbuf.data() + (size_t)q * nbytes, nbytes, k, approximate));
+        vc_query_stats st{};
+        worker.get_stat(st.n_main_reads, st.n_sub_reads, st.n_local_reads, st.radius);
+        stats.push_back(st);
+      }
+    } else {
+      results = worker.find_batch(qbuf.data(), nbytes, (uint32_t)n_query, k, approximate, &stats);
+    }
+    for (int q = 0; q < n_query; ++q) {
+      n_main_reads = stats[q].n_main_reads; n_sub_reads = stats[q].n_sub_reads; n_local_reads = stats[q].n_local_reads; radius = stats[q].radius;
       n_main_total += n_main_reads;
       n_local_total += n_local_reads;
       n_sub_total += n_sub_reads;
       radius_total += radius;
       if (print_results) {
-        std::cout << "query " << n_query << std::endl;
-        for (const auto& r : result) std::cout << r.image_id << " : " << r.dist << std::endl;
+        std::cout << "query " << q << std::endl;
+        for (const auto& r : results[q]) std::cout << r.image_id << " : " << r.dist << std::endl;
         std::cout << "stat n_main_reads : " << n_main_reads << " , n_sub_reads : " << n_sub_reads
                   << ", n_local_reads : " << n_local_reads << ", radius : " << radius << std::endl;
       }
-      n_query++;
-      if (n_query == 200) break;
     }
     fclose(f);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -326,6 +326,30 @@ class SearchWorker {
     for (uint32_t i = 0; i < cnt; ++i) result_.push_back({(uint32_t)(out[i] & 0xffffffffu), (uint32_t)(out[i] >> 32)});
     return result_;
   }
+  // The same for a BATCH of queries in one ABI call (n_query codes of nbytes each, back to back): the reference's drivers
+  // call find() once per query (distributed_image_search.cc:62-85, accuracy_test.cc:72-91); on the GPU a batch shares every
+  // launch, so 200 queries cost little more than one.  Results and per-query statistics exactly as n_query find() calls.
+  std::vector<std::list<search_result_st> > find_batch(const char* binary_codes, size_t nbytes, uint32_t n_query, int knn,
+                                                       bool approximate, std::vector<vc_query_stats>* stats = nullptr) {
+    if (nbytes != e_->nbytes() || e_->n_tables() == 0 || nbytes % e_->n_tables() != 0)   // :75 assert
+      throw EngineError(VC_ERR_INVALID, "find: nbytes must equal the engine's code size and divide by n_tables");
+    std::vector<std::list<search_result_st> > all(n_query);
+    if (n_query == 0) return all;
+    std::vector<uint64_t> out((size_t)n_query * knn);
+    std::vector<uint32_t> cnt(n_query);
+    std::vector<vc_query_stats> st(n_query);
+    e_->check(e_->search_knn(binary_codes, n_query, (uint32_t)knn, approximate ? VC_MODE_MIH_APPROX : VC_MODE_MIH_EXACT,
+                             VC_ORDER_FARTHEST_FIRST, out.data(), cnt.data(), st.data()));
+    for (uint32_t q = 0; q < n_query; ++q)
+      for (uint32_t i = 0; i < cnt[q]; ++i) {
+        const uint64_t v = out[(size_t)q * knn + i];
+        all[q].push_back({(uint32_t)(v & 0xffffffffu), (uint32_t)(v >> 32)});
+      }
+    result_ = all.back();
+    stat_ = st.back();
+    if (stats) *stats = st;
+    return all;
+  }
   std::list<search_result_st> get_knn() { return result_; }
   // search_worker.cc:24-30
   void get_stat(uint64_t& n_main_reads, uint64_t& n_sub_reads, uint64_t& n_local_reads, uint32_t& radius) {
