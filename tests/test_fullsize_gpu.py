@@ -249,3 +249,61 @@ def test_config2_m4_variant_streams_its_buckets_over_1e8_codes(vc, oracle):
             exp = oracle.linear_radius_slabbed(pool, n, bits, 34, q[sel], radius)
         for j, i in enumerate(sel):
             assert np.array_equal(mih[i], exp[j])
+
+
+def test_config4_1e9_codes_sharded_8_ways_through_the_c_abi(vc, oracle):
+    """BASELINE configs[3] in its shard arithmetic -- 128-bit codes, 1e9-code database split by id range into 8 shards of
+    125 M, per-shard top-100, one exchange, device merge -- through vc_sharded_* with the eight shards on the ONE GPU of
+    the test box (peer-copy exchange in place of the all-gather over xGMI).  Rows == the oracle's scan of the whole 1e9
+    codes for two queries, == a single engine holding everything for all."""
+    n, bits, k = 1_000_000_000, 128, 100
+    rng = np.random.default_rng(31)
+    q = rng.integers(0, 256, size=(8, bits // 8), dtype=np.uint8)
+    with vc.ShardedEngine(bits, capacity=n, n_shards=8, devices=[0], query_tile=8) as s:
+        s.add_synthetic(n, seed=34)
+        assert len(s) == n and s.exchange == vc.EXCHANGE_PEER_COPY
+        assert [s.shard_range(g) for g in range(8)] == [(g * 125_000_000, 125_000_000) for g in range(8)]
+        plant = [int(x) for x in rng.integers(0, n, size=4)]            # near-duplicates of items of four different shards
+        for i, g in enumerate(plant):
+            q[i] = _flip(s.get_code(g), rng.choice(bits, size=i + 1, replace=False), rng)
+        rows, cnt = s.search_knn(q, k)
+        assert np.all(cnt == k)
+        for i, g in enumerate(plant):
+            assert int(rows[i, 0]) == ((i + 1) << 32 | g)
+    with vc.Engine(bits, capacity=n, query_tile=8) as e:
+        e.add_synthetic(n, seed=34)
+        one, _ = e.search_knn(q, k)
+    assert np.array_equal(rows, one)
+    with oracle.Pool() as pool:
+        exp = oracle.linear_knn_slabbed(pool, n, bits, 34, q[[0, 7]], k)
+    assert np.array_equal(rows[[0, 7]], exp)
+
+
+def test_config5_4e9_codes_256bit_4096_queries_sharded_8_ways_on_one_device(vc, oracle):
+    """BASELINE configs[4] at FULL size: 256-bit codes, 4e9-code database (128 GB), 4096 queries per batch in one LDS query
+    tile per shard, eight id-range shards of 5e8 codes -- all eight resident on the one 288 GB GPU of the test box, searched
+    through vc_sharded_* (what eight GPUs do side by side, one after the other here; peer-copy exchange, device merge).
+    Planted neighbours from different shards come back first at their exact distance with their 32-bit global ids (up to
+    4e9 - 1), rows ascend, and two rows equal the oracle's scan of all 4e9 codes."""
+    n, bits, k, nq = 4_000_000_000, 256, 100, 4096
+    rng = np.random.default_rng(44)
+    q = rng.integers(0, 256, size=(nq, bits // 8), dtype=np.uint8)
+    with vc.ShardedEngine(bits, capacity=n, n_shards=8, devices=[0], query_tile=4096) as s:
+        s.add_synthetic(n, seed=34)
+        slots = [0, 1, 777, 2048, 4095]
+        plant = [5, 499_999_999, 500_000_000, 3_141_592_653, n - 1]   # shard edges, an id beyond 2^31, the last id
+        nflip = [0, 3, 7, 12, 30]
+        for sl, g, f in zip(slots, plant, nflip):
+            q[sl] = _flip(s.get_code(g), rng.choice(bits, size=f, replace=False), rng)
+        rows, cnt = s.search_knn(q, k)
+        assert np.all(cnt == k) and np.all(rows[:, 1:] > rows[:, :-1])
+        for sl, g, f in zip(slots, plant, nflip):
+            assert int(rows[sl, 0] & MASK) == g and int(rows[sl, 0] >> SH) == f
+        for sl in (5, 3000):                                          # reported distances are what the stored codes say
+            for j in (0, k - 1):
+                code = s.get_code(int(rows[sl, j] & MASK))
+                assert int(np.unpackbits(code ^ q[sl]).sum()) == int(rows[sl, j] >> SH)
+    sel = [777, 3000]
+    with oracle.Pool() as pool:
+        exp = oracle.linear_knn_slabbed(pool, n, bits, 34, q[sel], k)
+    assert np.array_equal(rows[sel], exp)

@@ -1480,8 +1480,12 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 //     the query's result ring with one atomic per wave.
 // Algorithmic bytes: probes x 8 (two offsets) + entries x B/8; measured by the kernel's own counters (vc_timing.mih_*).
 // =============================================================================================================
+#ifndef MS_U
 #define MS_U 8u                          // bucket entries per lane in flight
+#endif
+#ifndef MS_MAXP
 #define MS_MAXP 2048u                    // probes of one query (all tables, all shells) held in LDS
+#endif
 
 struct StreamParams {
   const uint64_t* queries;               // [nq][W]
@@ -1770,7 +1774,11 @@ __global__ void __launch_bounds__(256) mih_minsub_count_kernel(const uint64_t* _
 
 // sum the per-query work counters of one mih_query_kernel launch into the index-wide totals (vc_get_timing)
 __global__ void __launch_bounds__(256) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
-                                                              unsigned long long* __restrict__ totals) {
+                                                              unsigned long long* __restrict__ totals, const uint32_t* __restrict__ ctr,
+                                                              volatile uint32_t* __restrict__ host_ctr) {
+  // the launch's counters (unfinished queries, where the others stopped) go straight to pinned host memory: the host
+  // then only waits for the stream instead of queueing a copy behind it
+  if (host_ctr && threadIdx.x < 6) host_ctr[2 + threadIdx.x] = ctr[2 + threadIdx.x];
   __shared__ unsigned long long s_t[3];
   if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
   __syncthreads();
@@ -1913,7 +1921,8 @@ struct VcMihIndex {
   void* d_tile = nullptr;
   size_t tile_bytes = 0;
   uint32_t* d_lists = nullptr;   // 3 * MIH_QTILE + 4 counters
-  uint32_t* h_ctr = nullptr;     // pinned: the two counters the host reads back after every shell
+  uint32_t* h_ctr = nullptr;     // pinned: the counters the host reads back after every launch sequence
+  uint32_t* h_ctr_dev = nullptr; // its device-side alias (mapped): the query kernel's counters are stored there directly
   // measurement (vc_get_timing): event pairs around every mih_query_kernel launch, device totals of its work counters
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -2579,7 +2588,10 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
   hipError_t r = launch_query_kernel(p, W, nq, s);
   if (ev) (void)hipEventRecord(ev->second, s);
   if (r != hipSuccess) return r;
-  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(256), 0, s, p.st.work, nq, ix->d_totals);
+  // (k-NN launches only: heavy_ctr = the tile's counter block + 2; radius search has no counters to publish)
+  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(256), 0, s, p.st.work, nq, ix->d_totals,
+                     p.heavy_ctr ? (const uint32_t*)p.heavy_ctr - 2 : (const uint32_t*)nullptr,
+                     p.heavy_ctr ? (volatile uint32_t*)ix->h_ctr_dev : (volatile uint32_t*)nullptr);
   if (p.phase_dbg) {
     unsigned long long h[8];
     if (hipMemcpyAsync(h, p.phase_dbg, 64, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
@@ -2685,7 +2697,10 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   // stop multiplier: the reference's literal 4 (search_worker.cc:204); min(m,4) keeps m < 4 exact
   const uint32_t stop_mult = (ix->flags & VC_FLAG_REF_STOP_LITERAL4) ? 4u : std::min(ix->m, 4u);
   MihState st;
-  if (!ix->h_ctr) MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 32, hipHostMallocDefault));   // pageable memory makes the read-back a staged copy
+  if (!ix->h_ctr) {
+    MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 32, hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void**)&ix->h_ctr_dev, ix->h_ctr, 0) != hipSuccess) { (void)hipGetLastError(); ix->h_ctr_dev = nullptr; }
+  }   // pageable memory makes the read-back a staged copy
   uint32_t* h_ctr = ix->h_ctr;
 
   // Shells 0..r_last run inside ONE launch, one block per query (mih_query_kernel); the host reads ONE counter per
@@ -2733,8 +2748,8 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       const auto t_q = std::chrono::steady_clock::now();
       MIH_CHECK(hipMemsetAsync(d_ctr, 0, 32, s));
       MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
-      MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 24, hipMemcpyDeviceToHost, s));   // unfinished queries + where the others stopped
-      MIH_CHECK(hipStreamSynchronize(s));
+      if (!ix->h_ctr_dev) MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 24, hipMemcpyDeviceToHost, s));   // (else published by the reduce kernel)
+      MIH_CHECK(hipStreamSynchronize(s));   // unfinished queries + where the others stopped
       n_heavy = n_cur = h_ctr[2];
       if (S == 32 && qt >= 64)       // next launch: group up to shell 2 when most queries of this one needed it
         ix->group_hint = (uint64_t)(h_ctr[6] + h_ctr[7]) * 10 >= (uint64_t)qt * 6 ? 3u : 2u;
