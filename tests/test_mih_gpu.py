@@ -526,112 +526,3 @@ def test_radius_search_through_the_bucket_streaming_kernel(vc, oracle, monkeypat
             for i in range(0, nq, max(1, nq // 25)):
                 ores, _ = mo.radius(qq[i], m + 2)
                 assert np.array_equal(mih[i], ores), (nq, i)
-
-
-def _knn_both_ways(vc, monkeypatch, codes, bits, m, flags, q, k, approx=False, group=None):
-    """rows, counts and statistics of one k-NN call with VC_MIH_TILE=0 (mih_query_kernel alone) and =2 (tile pipeline)."""
-    out = {}
-    for flag in ("0", "2"):
-        monkeypatch.setenv("VC_MIH_TILE", flag)
-        if group is not None:
-            monkeypatch.setenv("VC_MIH_GROUP", str(group))
-        with vc.Engine(bits, capacity=codes.shape[0], n_tables=m, flags=flags) as e:
-            e.add_codes(codes)
-            e.build_index()
-            res, cnt, st = e.search_knn(q, k, mode=vc.MODE_MIH_APPROX if approx else vc.MODE_MIH_EXACT, with_stats=True)
-            out[flag] = (res, cnt, [(s.radius, s.n_sub_reads, s.n_local_reads, s.n_candidates) for s in st])
-    return out["0"], out["2"]
-
-
-@pytest.mark.parametrize("bits,m,fl,k,group", [
-    (128, 4, "", 100, 3), (128, 4, "", 100, 2), (128, 4, "", 1, 1), (128, 4, "bitmap", 20, 3), (64, 2, "", 20, 3),
-    (64, 2, "literal4", 20, 2), (256, 8, "", 100, 3), (512, 16, "", 10, 2), (128, 4, "approx", 10, 3),
-])
-def test_tile_pipeline_equals_the_query_kernel(vc, oracle, monkeypatch, bits, m, fl, k, group):
-    """Batches over 32-bit substrings run shells 0 .. group-1 through mih_tile_probe_kernel -> mih_tile_verify_kernel
-    and what is left through mih_query_kernel (VC_MIH_TILE=2: every batch): rows, counts and every statistic equal
-    mih_query_kernel's own (VC_MIH_TILE=0) and the oracle's.  Queries at 0 .. 14 flips: some stop in shell 0, most in
-    shells 1-2 (inside the pipeline), some in 3-4 (continued from the handed-over state)."""
-    n = 60000
-    rng = np.random.default_rng(bits * 7 + m + k + group)
-    flags = {"": 0, "bitmap": vc.FLAG_USE_BITMAP, "literal4": vc.FLAG_REF_STOP_LITERAL4, "approx": 0}[fl]
-    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=300, max_flips=10)
-    q = np.concatenate([_near_queries(codes, 24, rng, 4), _near_queries(codes, 12, rng, 14)])
-    a, b = _knn_both_ways(vc, monkeypatch, codes, bits, m, flags, q, k, approx=fl == "approx", group=group)
-    assert np.array_equal(a[1], b[1])
-    assert np.array_equal(a[0], b[0])
-    assert a[2] == b[2]
-    assert len({s[0] for s in b[2]}) >= 2                      # more than one stop shell in the batch
-    mo = oracle.MihOracle(codes, m, key_mode=1)
-    stop_mult = 4 if fl in ("literal4", "approx") else min(m, 4)
-    for i in range(0, len(q), 5):
-        ores, ost = mo.find(q[i], k, approximate=fl == "approx", use_bitmap=fl == "bitmap", stop_mult=stop_mult)
-        g = b[0][i, : b[1][i]]
-        if fl == "approx":
-            assert np.array_equal(g >> SH, np.sort(ores) >> SH)
-        else:
-            _check_contract(g, ores)
-        assert b[2][i][0] == ost.radius and b[2][i][1] == ost.n_sub_reads and b[2][i][3] == ost.n_distinct
-
-
-def test_tile_pipeline_rows_that_overflow_are_redone_by_the_query_kernel(vc, oracle, monkeypatch):
-    """a database that fills the whole radius-2 ball of every substring around one centre: ~2 000 non-empty buckets per
-    query, more than a row of the pipeline's bucket lists holds (1 024) -> the query is redone from shell 0 by
-    mih_query_kernel; mixed with ordinary queries in one batch."""
-    n, bits, m, k = 50000, 128, 4, 50
-    rng = np.random.default_rng(12)
-    centre = rng.integers(0, 256, size=16, dtype=np.uint8)
-    codes = np.tile(centre, (n, 1))
-    for i in range(n // 2):                                     # half the items: <= 2 flips in each 32-bit substring
-        for t in range(m):
-            for _ in range(rng.integers(0, 3)):
-                b = rng.integers(0, 32)
-                codes[i, t * 4 + b // 8] ^= np.uint8(1 << (b % 8))
-    codes[n // 2:] = oracle.gen_codes(n - n // 2, bits, 5, kind=1, n_centres=100, max_flips=8)
-    q = np.concatenate([centre[None, :], _near_queries(codes[n // 2:], 6, rng, 3), centre[None, :]])
-    q[-1, 3] ^= 0x10
-    a, b = _knn_both_ways(vc, monkeypatch, codes, bits, m, 0, q, k, group=3)
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
-    mo = oracle.MihOracle(codes, m, key_mode=1)
-    for i in (0, 1, len(q) - 1):
-        ores, ost = mo.find(q[i], k, stop_mult=4)
-        _check_contract(b[0][i, : b[1][i]], ores)
-        assert (b[2][i][0], b[2][i][1], b[2][i][3]) == (ost.radius, ost.n_sub_reads, ost.n_distinct)
-
-
-def test_tile_pipeline_hands_far_queries_to_the_multi_block_shells(vc, oracle, monkeypatch):
-    """uniform random codes, k-th neighbour ~40 bits away: nothing stops inside the pipeline, the continuation in
-    mih_query_kernel runs shells 3..4 and hands over to the multi-block shells; near queries in the same batch."""
-    n, bits, m, k = 3000, 128, 4, 3
-    codes = oracle.gen_codes(n, bits, 77)
-    rng = np.random.default_rng(1)
-    q = np.stack([codes[5], rng.integers(0, 256, size=16, dtype=np.uint8), codes[100], rng.integers(0, 256, size=16, dtype=np.uint8)])
-    q[2, 0] ^= 1
-    a, b = _knn_both_ways(vc, monkeypatch, codes, bits, m, 0, q, k)
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
-    assert max(s[0] for s in b[2]) > 4
-
-
-def test_tile_pipeline_large_batch_default_path(vc, oracle, monkeypatch):
-    """700 queries: VC_MIH_TILE=1 sends a batch of >= 512 through the pipeline; equal to
-    mih_query_kernel alone on every row and statistic, and to the linear scan on distances."""
-    n, bits, m, k = 200000, 128, 4, 100
-    rng = np.random.default_rng(5)
-    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=400, max_flips=10)
-    q = _near_queries(codes, 700, rng, 6)
-    out = {}
-    for flag in ("0", None):
-        if flag is None:
-            monkeypatch.setenv("VC_MIH_TILE", "1")
-        else:
-            monkeypatch.setenv("VC_MIH_TILE", flag)
-        with vc.Engine(bits, capacity=n, n_tables=m) as e:
-            e.add_codes(codes)
-            e.build_index()
-            res, cnt, st = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
-            res2, cnt2 = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT)         # second call: adapted group depth
-            lin, _ = e.search_knn(q, k)
-            assert np.array_equal(res, res2) and np.array_equal(cnt, cnt2)
-            assert np.array_equal(res >> SH, lin >> SH)
-            out[flag] = (res, cnt, [(s.radius, s.n_sub_reads, s.n_candidates) for s in st])
-    assert np.array_equal(out["0"][0], out[None][0]) and np.array_equal(out["0"][1], out[None][1]) and out["0"][2] == out[None][2]

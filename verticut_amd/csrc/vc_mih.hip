@@ -642,7 +642,6 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 #define MQ_TAG_SHIFT 62
 #define MQ_TAG_MASK (3ull << MQ_TAG_SHIFT)
 #define MQ_MAX_GROUP 3u
-#define MQ_SLOT_REDO 0x80000000u        // slot_list entry: run the query from shell 0 (its bucket list outgrew the tile pipeline's row)
 static __host__ __device__ inline uint32_t mq_hist_bins(uint32_t W) { return (W * 64u + 1u + 7u) & ~7u; }
 
 struct QueryKernelParams {
@@ -663,15 +662,9 @@ struct QueryKernelParams {
   uint32_t* heavy_ctr;
   uint64_t* out;               // k-NN: [nq][k] rows
   uint32_t* out_cnt;
-  unsigned long long* phase_dbg;  // dev (VC_MIH_PHASES): [8] phase times of mih_query_kernel, summed over the launch
+  unsigned long long* phase_dbg;  // dev (VC_MIH_PHASES): [8] phase times of mih_query_kernel, summed over the launch; [8..13] block lifetimes by stop shell (0..4, handed over), [16..21] their counts, [24] start of the first block, [25..30] latest end by stop shell
   uint32_t group;              // k-NN, 32-bit substrings: shells 0 .. group-1 share the first pass (1 = one shell per pass)
   uint32_t* radius_hist;       // k-NN: [4] queries of the launch by the shell they stopped in (0, 1, 2, later / handed over)
-  // continuation of queries the tile pipeline (mih_tile_*_kernel) left: block b serves slot_list[b] when b < *slot_count
-  // (the grid is an upper bound: no host round trip before the launch); r_first > 0 resumes at that shell from the state
-  // handed over (st.topk / count / thresh / seen / sub / loc), r_first = 0 runs the listed queries from scratch
-  const uint32_t* slot_list;
-  const uint32_t* slot_count;
-  uint32_t r_first;
 };
 
 __device__ __forceinline__ uint32_t mq_unrank(const uint32_t* sb, uint32_t j, uint32_t r, uint32_t s) {
@@ -805,14 +798,19 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   __shared__ uint32_t s_segstart[28], s_segh[27], s_segmask[27], s_segr[27], s_nseg;
   __shared__ uint64_t s_thresh;
 
-  if (p.slot_count && blockIdx.x >= *p.slot_count) return;
-  const uint32_t slot_entry = p.slot_list ? p.slot_list[blockIdx.x] : blockIdx.x;
-  const uint32_t slot = slot_entry & ~MQ_SLOT_REDO;
-  const uint32_t r_first = (slot_entry & MQ_SLOT_REDO) ? 0u : p.r_first;   // (block-uniform)
+  const uint32_t slot = blockIdx.x;
   const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
   const uint32_t s = p.sbits, m = p.m;
   const uint32_t smask = s == 32 ? 0xFFFFFFFFu : ((1u << s) - 1u);
   const bool knn = p.mode != MQ_MODE_RADIUS;
+  // Result / state pointers are read from the kernel-argument segment where they are used (the end of a query, once):
+  // as ordinary by-value arguments they sat in ~40 SGPRs from entry to exit and were spilled to VGPR lanes around every loop.
+  auto cold = [&]() {
+    const __attribute__((address_space(4))) QueryKernelParams* q =
+        (const __attribute__((address_space(4))) QueryKernelParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));   // opaque: the loads stay behind this point
+    return q;
+  };
   const unsigned long long t_entry = p.phase_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   uint64_t qw[W];
@@ -840,7 +838,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   if (tid == 0) {
     s_nh = 0;
     s_ncand = 0;
-    s_thresh = knn ? VC_PACK_INF : vc_pack(p.radius + 1, 0);
+    s_thresh = knn ? VC_PACK_INF : vc_pack(cold()->radius + 1, 0);
   }
   __syncthreads();
   if (s == 32) {   // E_j[t] = { x < 2^MQ_LO : popcount(x ^ qlo_t) = j }; radius search: balls B_j = E_0 | ... | E_j
@@ -887,14 +885,21 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   uint32_t kk = 0;                 // radius mode: sorted results in s_buf[0..kk)           (block-uniform)
   bool spilled = false;            // radius mode: results went to the global ring unsorted (block-uniform)
   uint32_t ring_fill = 0;          // radius mode: entries already in the global ring       (block-uniform)
-  unsigned long long sub = 0, loc = 0;   // get_stat counters of table 0 (block-uniform)
-  unsigned long long w_probes = 0, w_hits = 0, w_entries = 0;   // algorithmic work of this query (block-uniform)
-  uint64_t* const ring = p.st.ring + (uint64_t)slot * p.cap;   // radius mode only (k-NN hand-over goes through st.topk)
+  // get_stat counters of table 0 (sub, loc) and the algorithmic work of this query (probes, non-empty buckets, entries): thread 0's,
+  // in LDS -- as block-uniform locals they were ten more scalar registers alive from entry to exit
+  __shared__ unsigned long long s_stat[5];
+  unsigned long long& sub = s_stat[0];
+  unsigned long long& loc = s_stat[1];
+  unsigned long long& w_probes = s_stat[2];
+  unsigned long long& w_hits = s_stat[3];
+  unsigned long long& w_entries = s_stat[4];
+  if (tid < 5) s_stat[tid] = 0;   // (a barrier follows before the first use)
+  auto ring_row = [&]() { return cold()->st.ring + (uint64_t)slot * cold()->cap; };   // radius mode only (k-NN hand-over goes through st.topk)
   auto put_work = [&]() {
     if (tid == 0) {
-      p.st.work[slot * 4 + 0] = w_probes;
-      p.st.work[slot * 4 + 1] = w_hits;
-      p.st.work[slot * 4 + 2] = w_entries;
+      cold()->st.work[slot * 4 + 0] = w_probes;
+      cold()->st.work[slot * 4 + 1] = w_hits;
+      cold()->st.work[slot * 4 + 2] = w_entries;
     }
   };
 
@@ -916,9 +921,10 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   // ---- radius mode: move the LDS results to the global ring (unsorted; the count keeps running past cap)
   auto flush_ring = [&]() {
     __syncthreads();
-    const uint32_t nc = s_ncand;
+    const uint32_t nc = s_ncand, rcap = cold()->cap;
+    uint64_t* const ring = ring_row();
     for (uint32_t i = tid; i < nc; i += MQ_BLK)
-      if (ring_fill + i < p.cap) ring[ring_fill + i] = s_buf[i];
+      if (ring_fill + i < rcap) ring[ring_fill + i] = s_buf[i];
     ring_fill += nc;
     spilled = true;
     __syncthreads();
@@ -1012,8 +1018,10 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     }
     if (tid == 0) s_pref[H] = total;
     __syncthreads();
-    w_hits += H;
-    w_entries += total;
+    if (tid == 0) {
+      w_hits += H;
+      w_entries += total;
+    }
     tick(3);
 
     uint32_t seen_acc = 0, seen_acc1 = 0, seen_acc2 = 0;   // per shell class (wave-uniform)
@@ -1322,25 +1330,6 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 
   tick(1);                         // (phase 0 = set-up: tables, binomials, masks -- but the phase clock starts after them)
   const uint32_t S = s;            // loop bound radius <= n_local_bytes_ * 8 (search_worker.cc:170)
-  if (knn && r_first) {            // resume: the state handed over after shell r_first - 1 (sorted top-k, counters)
-    const uint32_t kin = min(p.st.count[slot], p.k);
-    for (uint32_t i = tid; i < kin; i += MQ_BLK) {
-      const uint64_t v = p.st.topk[(uint64_t)slot * p.k + i];
-      s_buf[i] = v;
-      atomicAdd(&s_hist[(uint32_t)(v >> 32)], 1u);
-    }
-    sub = p.st.sub[slot];
-    loc = p.st.loc[slot];
-    if (tid == 0) {
-      s_ncand = kin;
-      s_seenc[0] = (uint32_t)p.st.seen[slot];
-      // the hand-over threshold is the k-th best itself ("append iff better", the multi-block kernels' rule, which keep
-      // the committed top-k apart); here the committed entries live in the same buffer, so the bound is exclusive
-      const uint64_t th = p.st.thresh[slot];
-      s_thresh = th == VC_PACK_INF ? th : th + 1;
-    }
-    __syncthreads();
-  }
   if (!knn) {
     // fixed-radius neighbour search, every item within the full distance R kept.  Pigeonhole with the sharper radii of
     // multi-index hashing: R = m q + a  =>  tables 0..a search substring radius q, tables a+1..m-1 only q - 1 (were every
@@ -1348,46 +1337,49 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     // (lowest table among those with the smallest substring distance) needs no change: the radii do not increase with the
     // table number, so the owner of an item within R always lies inside its own radius.  configs[1] (R = 8, m = 2: radii
     // 4 and 3) probes 12 951 instead of 21 806 bitmap sectors per query.
-    const uint32_t n_big = min(p.n_big, m);
+    const uint32_t n_big = min(cold()->n_big, m), small_shells = cold()->small_shells;
     if (s == 32) {
       tb_first = 0; tb_count = n_big;
       plan32(p.r_last, p.r_last, true);
       scan32();
-      if (n_big < m && p.small_shells) {
+      if (n_big < m && small_shells) {
         tb_first = n_big; tb_count = m - n_big;
-        plan32(p.small_shells - 1, p.small_shells - 1, true);
+        plan32(small_shells - 1, small_shells - 1, true);
         scan32();
       }
     } else {
       for (uint32_t r = 0; r <= p.r_last; ++r) {
-        tb_first = 0; tb_count = r < p.small_shells ? m : n_big;
+        tb_first = 0; tb_count = r < small_shells ? m : n_big;
         scan_direct(r);
       }
     }
     tb_first = 0; tb_count = m;
     if (s_nh) drain();
     __syncthreads();
-    for (uint32_t r = 0; r <= p.r_last; ++r) w_probes += (unsigned long long)(r < p.small_shells ? m : n_big) * c_binom[s][r];
+    if (tid == 0)
+      for (uint32_t r = 0; r <= p.r_last; ++r) w_probes += (unsigned long long)(r < small_shells ? m : n_big) * c_binom[s][r];
     put_work();
     if (!spilled) {
       merge();                                       // sorts the LDS results (kk = their number)
+      const uint32_t rcap = cold()->cap;
+      uint64_t* const ring = ring_row();
       for (uint32_t i = tid; i < kk; i += MQ_BLK)
-        if (i < p.cap) ring[i] = s_buf[i];
+        if (i < rcap) ring[i] = s_buf[i];
       if (tid == 0) {
-        p.st.count[slot] = kk;
-        p.st.topn[slot] = kk <= p.cap ? 1u : 0u;     // 1 = the ring segment is already sorted
+        cold()->st.count[slot] = kk;
+        cold()->st.topn[slot] = kk <= rcap ? 1u : 0u;     // 1 = the ring segment is already sorted
       }
     } else {
       flush_ring();
       if (tid == 0) {
-        p.st.count[slot] = ring_fill;
-        p.st.topn[slot] = 0;
+        cold()->st.count[slot] = ring_fill;
+        cold()->st.topn[slot] = 0;
       }
     }
     return;
   }
 
-  for (uint32_t r = r_first; r <= p.r_last;) {
+  for (uint32_t r = 0; r <= p.r_last;) {
     // The first pass of 32-bit substrings covers shells 0 .. group-1 at once (their 1 + 26 (+ 326) granules per table):
     // candidates are tagged with their shell class and counted per class, the stop rule is evaluated shell by shell
     // afterwards -- no result or statistic changes, a scan / drain round is saved per grouped shell
@@ -1419,13 +1411,15 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       }
       // get_stat counters of table 0 (rank 0's, search_worker.cc:24-30): every leaf is a bitmap test when the bitmap
       // is attached (:239) and a get only where the bit is set (:245); without it every leaf is a get
-      const unsigned long long leaves = c_binom[s][rr];
-      w_probes += leaves * m;
-      if (p.flags & VC_FLAG_USE_BITMAP) {
-        loc += leaves;
-        sub += s_hits0c[0];
-      } else {
-        sub += leaves;
+      if (tid == 0) {
+        const unsigned long long leaves = c_binom[s][rr];
+        w_probes += leaves * m;
+        if (p.flags & VC_FLAG_USE_BITMAP) {
+          loc += leaves;
+          sub += s_hits0c[0];
+        } else {
+          sub += leaves;
+        }
       }
       const uint32_t seen = s_seenc[0];
       __syncthreads();
@@ -1449,16 +1443,23 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         tick(5);
         const uint32_t kout = finish_sort(cls);   // classes beyond the shell the loop stops in were never seen by it
         put_work();
-        for (uint32_t i = tid; i < p.k; i += MQ_BLK) p.out[(uint64_t)slot * p.k + i] = i < kout ? s_buf[i] : VC_PACK_INF;
+        for (uint32_t i = tid; i < p.k; i += MQ_BLK) cold()->out[(uint64_t)slot * p.k + i] = i < kout ? s_buf[i] : VC_PACK_INF;
         if (tid == 0) {
-          p.out_cnt[slot] = kout;
-          p.st.radius[slot] = rr;     // find() returns radius - 1 = last shell searched
-          p.st.seen[slot] = seen;
-          p.st.sub[slot] = sub;
-          p.st.loc[slot] = loc;
-          if (p.radius_hist) atomicAdd(&p.radius_hist[min(rr, 3u)], 1u);
+          cold()->out_cnt[slot] = kout;
+          cold()->st.radius[slot] = rr;     // find() returns radius - 1 = last shell searched
+          cold()->st.seen[slot] = seen;
+          cold()->st.sub[slot] = sub;
+          cold()->st.loc[slot] = loc;
+          if (cold()->radius_hist) atomicAdd(&cold()->radius_hist[min(rr, 3u)], 1u);
         }
         tick(6);
+        if (p.phase_dbg && tid == 0) {
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          atomicAdd(&p.phase_dbg[8 + min(rr, 4u)], now - t_entry);
+          atomicAdd(&p.phase_dbg[16 + min(rr, 4u)], 1ull);
+          atomicMin(&p.phase_dbg[24], t_entry);
+          atomicMax(&p.phase_dbg[25 + min(rr, 4u)], now);
+        }
         return;
       }
       __syncthreads();
@@ -1475,613 +1476,32 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   // not finished: hand the query to the multi-block shells (state exactly as mih_commit_kernel leaves it)
   const uint32_t kout = finish_sort(0);
   put_work();
-  for (uint32_t i = tid; i < kout; i += MQ_BLK) p.st.topk[(uint64_t)slot * p.k + i] = s_buf[i];   // mih_seed_ring_kernel moves it into the ring
+  for (uint32_t i = tid; i < kout; i += MQ_BLK) cold()->st.topk[(uint64_t)slot * p.k + i] = s_buf[i];   // mih_seed_ring_kernel moves it into the ring
   if (tid == 0) {
-    p.st.count[slot] = kout;
-    p.st.prev[slot] = kout;
-    p.st.thresh[slot] = kout == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
-    p.st.seen[slot] = s_seenc[0];
-    p.st.sub[slot] = sub;
-    p.st.loc[slot] = loc;
-    p.st.radius[slot] = 0;
-    p.st.topn[slot] = kout;
-    p.heavy_list[atomicAdd(p.heavy_ctr, 1u)] = slot;
-    if (p.radius_hist) atomicAdd(&p.radius_hist[3], 1u);
+    cold()->st.count[slot] = kout;
+    cold()->st.prev[slot] = kout;
+    cold()->st.thresh[slot] = kout == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
+    cold()->st.seen[slot] = s_seenc[0];
+    cold()->st.sub[slot] = sub;
+    cold()->st.loc[slot] = loc;
+    cold()->st.radius[slot] = 0;
+    cold()->st.topn[slot] = kout;
+    cold()->heavy_list[atomicAdd(cold()->heavy_ctr, 1u)] = slot;
+    if (cold()->radius_hist) atomicAdd(&cold()->radius_hist[3], 1u);
     // what the radius loop may still cost this query: the k-th distance so far bounds the true one from above, so the loop
     // ends by shell floor(D_bound / mult) at the latest (search_worker.cc:201-205); all shells when k items are not found yet
     const uint32_t r_end = kout == p.k ? min(S, (uint32_t)(s_buf[p.k - 1] >> 32) / max(p.stop_mult, 1u)) : S;
     unsigned long long pred = 0;
     for (uint32_t r = p.r_last + 1; r <= r_end; ++r) pred += (unsigned long long)m * c_binom[s][r];
-    p.st.work[slot * 4 + 3] = pred;
-  }
-}
-
-// =============================================================================================================
-// Tile pipeline -- k-NN batches over 32-bit substrings (the reference's native shape), shells 0 .. group-1.
-// mih_query_kernel runs a query's whole chain in one block: ~13 dependent memory round trips with barriers in between,
-// four blocks per CU (128 VGPRs, 35 KB of LDS) -- latency-bound at a sixth of the random-sector rate.  A BATCH does not
-// need one query's chain to be short, only many chains in flight, so the first `group` shells are split by what they
-// touch, one specialised kernel each, every one small enough for 6-8 waves per SIMD:
-//   mih_tile_probe_kernel   ONE WAVE per query (no workgroup barrier after the table views are loaded): per-query masks,
-//                           granule scan of shells 0 .. group-1 of every table (search_worker.cc:230-246's leaves, by
-//                           granule as above), bucket directory (rank -> offset, length); writes the query's non-empty
-//                           buckets {entry offset, length, table | substring distance << 8} to its row of `blist`;
-//   mih_tile_verify_kernel  one block per query: bucket list -> prefix sums -> balanced verify of the entries (full and
-//                           per-substring distances, owner rule), candidates tagged with their shell class, stop rule
-//                           shell by shell (search_worker.cc:201-205 / :136-137), final order, output row + statistics --
-//                           the same candidate buffer / histogram scheme as mih_query_kernel, whose helpers it shares;
-//   mih_query_kernel        continues the few queries that are not finished after shell group-1 (slot_list, r_first =
-//                           group, state handed over like to the multi-block shells) and redoes from shell 0 the ones whose
-//                           bucket list outgrew TP_HCAP (bit 31 of the list entry).
-// Results and statistics are those of mih_query_kernel on the same queries (tests/test_mih_gpu.py runs both).
-// =============================================================================================================
-#define TP_HCAP 1024u                    // buckets per query the probe stage hands to the verify stage
-#define TP_HM 256u                       // per-wave LDS hit list of the probe stage
-#define TP_HFLUSH 192u
-#ifndef TP_G
-#define TP_G 4u                          // granules per lane per pass
-#endif
-#ifndef TP_WAVES
-#define TP_WAVES 6                       // waves per SIMD the probe stage is compiled for
-#endif
-#define TP_MAXSEG 8u                     // (shell, |hi|) segments of shells 0..2: 6
-#ifndef TP_LO
-#define TP_LO 7u
-#endif
-#define TV_H 512u                        // buckets of one verify chunk (LDS)
-#ifndef TV_EPT
-#define TV_EPT 2u                        // bucket entries per thread and round
-#endif
-#define TV_ROUND (MQ_BLK * TV_EPT)
-#ifndef TV_WAVES
-#define TV_WAVES 6
-#endif
-
-struct TileParams {
-  const uint64_t* cols;
-  uint64_t stride, n;
-  const VcTableView* tables;
-  const uint64_t* queries;     // [nq][W]
-  MihState st;
-  uint32_t nq, m, id_base, flags, k, mode, stop_mult;
-  uint32_t group;              // shells 0 .. group-1 run through the pipeline (1..MQ_MAX_GROUP)
-  uint32_t r_last;             // last shell of the one-block-per-query stage as a whole (group - 1 <= r_last)
-  uint32_t buf_entries;        // verify stage: LDS candidate buffer (power of two, >= MQ_MAX_GROUP * k + TV_ROUND)
-  uint4* blist;                // [nq][TP_HCAP] {entry offset, bucket length, table | substring distance << 8, -}
-  uint32_t* bhead;             // [nq][8] buckets written | entries | table 0's set leaves of shell 0, 1, 2 | overflow | - | -
-  uint32_t* cont_list;         // queries mih_query_kernel continues (| MQ_SLOT_REDO: from shell 0)
-  uint32_t* cont_ctr;
-  uint32_t* heavy_list;        // group - 1 == r_last: unfinished queries go straight to the multi-block shells
-  uint32_t* heavy_ctr;
-  uint64_t* out;               // [nq][k]
-  uint32_t* out_cnt;
-  uint32_t* radius_hist;
-  unsigned long long* phase_dbg;  // dev (VC_MIH_PHASES): [16] phase times, 10 ns ticks summed over the launch: probe stage 0..3, verify stage 8..13
-};
-
-__device__ __forceinline__ void mw_sync() {   // orders one wave's LDS traffic for the compiler (the hardware keeps it in order)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-static __host__ __device__ inline size_t tp_wave_words(uint32_t m, uint32_t lo) {
-  return (size_t)2 * TP_HM + (size_t)m * (lo + 1) * ((1u << lo) / 32u) + 4 * TP_MAXSEG + 4;
-}
-static __host__ __device__ inline size_t tp_shared_bytes(uint32_t m) { return ((size_t)m * sizeof(VcTableView) + 15) & ~(size_t)15; }
-
-template <int W, uint32_t LO>
-__global__ void __launch_bounds__(256, TP_WAVES) mih_tile_probe_kernel(const TileParams p) {
-  constexpr uint32_t HI = 32u - LO, GW = (1u << LO) / 32u, NJ = LO + 1u;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
-  const uint32_t m = p.m;
-  VcTableView* s_tv = (VcTableView*)smem;
-  uint32_t* wb = (uint32_t*)(smem + tp_shared_bytes(m)) + (size_t)wave * tp_wave_words(m, LO);
-  uint32_t* hkey = wb;                               // [TP_HM] bucket key
-  uint32_t* hmeta = hkey + TP_HM;                    // [TP_HM] table | substring distance << 8
-  uint32_t* mask = hmeta + TP_HM;                    // [m][NJ][GW]
-  uint32_t* segstart = mask + m * NJ * GW;           // [TP_MAXSEG + 1] (+ segment count behind)
-  uint32_t* segh = segstart + TP_MAXSEG + 2;         // [TP_MAXSEG] |hi| of the segment
-  uint32_t* segr = segh + TP_MAXSEG;                 // [TP_MAXSEG] shell of the segment (low flips j = r - h)
-
-  for (uint32_t i = threadIdx.x; i < m * (sizeof(VcTableView) / 4); i += blockDim.x) ((uint32_t*)s_tv)[i] = ((const uint32_t*)p.tables)[i];
-  __syncthreads();                                   // the only workgroup barrier: the table views are shared by the four waves
-  const uint32_t slot = blockIdx.x * (blockDim.x / VC_WAVE) + wave;
-  if (slot >= p.nq) return;
-  unsigned long long ph_last = p.phase_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  uint32_t ph_cur = 0;
-  auto tick = [&](uint32_t next) {   // (wave-uniform)
+    cold()->st.work[slot * 4 + 3] = pred;
     if (p.phase_dbg) {
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      if (lane == 0) atomicAdd(&p.phase_dbg[ph_cur], now - ph_last);
-      ph_last = now;
-      ph_cur = next;
-    }
-  };
-
-  uint64_t qw[W];
-#pragma unroll
-  for (int j = 0; j < W; ++j) qw[j] = p.queries[(uint64_t)slot * W + j];
-  auto qkey = [&](uint32_t t) {
-    const uint32_t bp = t * 32u;
-    uint32_t v = 0;
-#pragma unroll
-    for (int j = 0; j < W; ++j)
-      if ((uint32_t)j == (bp >> 6)) v = (uint32_t)(qw[j] >> (bp & 63));
-    return v;
-  };
-
-  for (uint32_t i = lane; i < m * NJ * GW; i += VC_WAVE) mask[i] = 0;
-  if (lane == 0) {   // segments of the pass: (shell r, |hi| = h), low flips j = r - h <= LO
-    uint32_t ns = 0, start = 0;
-    for (uint32_t r = 0; r < p.group; ++r)
-      for (uint32_t h = 0; h <= r; ++h) {
-        if (r - h > LO || h > HI) continue;
-        segstart[ns] = start;
-        segh[ns] = h;
-        segr[ns] = r;
-        start += h == 0 ? 1u : (h == 1 ? HI : HI * (HI - 1) / 2);
-        ++ns;
-      }
-    segstart[ns] = start;
-    segstart[TP_MAXSEG + 1] = ns;
-  }
-  mw_sync();
-  for (uint32_t i = lane; i < (m << LO); i += VC_WAVE) {   // E_j[t] = { x < 2^LO : popcount(x ^ qlo_t) = j }
-    const uint32_t t = i >> LO, x = i & ((1u << LO) - 1u);
-    const uint32_t j = __popc(x ^ (qkey(t) & ((1u << LO) - 1u)));
-    atomicOr(&mask[(t * NJ + j) * GW + (x >> 5)], 1u << (x & 31));
-  }
-  mw_sync();
-
-  uint4* const row = p.blist + (uint64_t)slot * TP_HCAP;
-  uint32_t nh = 0;                         // LDS hit list fill (wave-uniform; may exceed TP_HM until flushed)
-  uint32_t nb = 0;                         // buckets of this query so far (wave-uniform; may exceed TP_HCAP: overflow)
-  uint32_t ent = 0;                        // bucket entries, this lane's share
-  uint32_t hits0[MQ_MAX_GROUP] = {0, 0, 0};   // table 0's leaves whose bitmap bit is set, per shell (VC_FLAG_USE_BITMAP statistics)
-
-  // ---- bucket directory for the listed hits (see mih_query_kernel's drain), rows written behind what the query already has
-  auto flush = [&]() {
-    mw_sync();
-    tick(2);
-    const uint32_t H = min(nh, TP_HM);
-    for (uint32_t i = lane; i < H; i += VC_WAVE) {
-      const uint32_t key = hkey[i], meta = hmeta[i];
-      const VcTableView& tv = s_tv[meta & 0xFFu];
-      const uint32_t blk = key >> 8, wq = (key >> 5) & 7u;
-      const uint4* bw = reinterpret_cast<const uint4*>(tv.bitmap + ((uint64_t)blk << 3));
-      const uint4 b0 = bw[0], b1 = bw[1];
-      const uint2 d0 = tv.blockoff[blk], d1 = tv.blockoff[blk + 1];
-      const uint32_t wv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      uint32_t below = 0, all = 0;
-#pragma unroll
-      for (uint32_t j = 0; j < 8; ++j) {
-        all += __popc(wv[j]);
-        below += j < wq ? __popc(wv[j]) : (j == wq ? __popc(wv[j] & ((1u << (key & 31)) - 1u)) : 0u);
-      }
-      uint32_t a, len;
-      if (d1.x - d0.x == all) {             // every bucket of the block holds one entry
-        a = d0.x + below;
-        len = 1;
-      } else {
-        const uint32_t rk = d0.y + below;
-        a = tv.offsets[rk];
-        len = tv.offsets[rk + 1] - a;
-      }
-      ent += len;
-      if (nb + i < TP_HCAP) row[nb + i] = make_uint4(a, len, meta, 0u);
-    }
-    nb += H;
-    nh = 0;
-    mw_sync();
-    tick(1);
-  };
-
-  const uint32_t nseg = __builtin_amdgcn_readfirstlane(segstart[TP_MAXSEG + 1]);
-  const uint32_t per_table = __builtin_amdgcn_readfirstlane(segstart[nseg]);
-  const uint32_t total = per_table * m;
-  tick(1);
-  for (uint32_t base = 0; base < total; base += VC_WAVE * TP_G) {
-    const uint32_t idx0 = base + lane * TP_G;
-    uint32_t t = 0, rem = 0, seg = 0, hi = 0;
-    if (idx0 < total) {
-      t = idx0 / per_table;
-      rem = idx0 - t * per_table;
-      while (rem >= segstart[seg + 1]) ++seg;
-      hi = mq_unrank(nullptr, rem - segstart[seg], segh[seg], HI);   // |hi| <= 2: closed form, no table
-    }
-    uint4 v[TP_G][GW / 4];
-    uint32_t gr[TP_G], meta0[TP_G];   // meta0 = table | |hi| << 8 | shell << 16 | low flips << 24
-#pragma unroll
-    for (uint32_t g = 0; g < TP_G; ++g) {
-      const uint32_t idx = idx0 + g;
-      gr[g] = 0; meta0[g] = 0;
-#pragma unroll
-      for (uint32_t c = 0; c < GW / 4; ++c) v[g][c] = make_uint4(0, 0, 0, 0);
-      if (idx < total) {
-        if (g) {
-          ++rem;
-          if (rem == per_table) {
-            ++t;
-            rem = 0;
-            seg = 0;
-            hi = 0;
-          } else if (rem == segstart[seg + 1]) {
-            ++seg;
-            hi = (1u << segh[seg]) - 1u;
-          } else {
-            hi = vc_next_comb(hi);
-          }
-        }
-        gr[g] = (qkey(t) >> LO) ^ hi;
-        meta0[g] = t | (segh[seg] << 8) | (segr[seg] << 16) | ((segr[seg] - segh[seg]) << 24);
-        const uint4* gp = reinterpret_cast<const uint4*>(s_tv[t].bitmap + (uint64_t)gr[g] * GW);
-#pragma unroll
-        for (uint32_t c = 0; c < GW / 4; ++c) v[g][c] = gp[c];
-      }
-    }
-    uint32_t w[TP_G][GW];
-    uint32_t cnt = 0;
-#pragma unroll
-    for (uint32_t g = 0; g < TP_G; ++g) {
-      const uint32_t* mk = mask + ((meta0[g] & 0xFFu) * NJ + (meta0[g] >> 24)) * GW;
-      uint32_t c = 0;
-#pragma unroll
-      for (uint32_t cc = 0; cc < GW / 4; ++cc) {
-        w[g][4 * cc + 0] = v[g][cc].x & mk[4 * cc + 0];
-        w[g][4 * cc + 1] = v[g][cc].y & mk[4 * cc + 1];
-        w[g][4 * cc + 2] = v[g][cc].z & mk[4 * cc + 2];
-        w[g][4 * cc + 3] = v[g][cc].w & mk[4 * cc + 3];
-        c += __popc(w[g][4 * cc + 0]) + __popc(w[g][4 * cc + 1]) + __popc(w[g][4 * cc + 2]) + __popc(w[g][4 * cc + 3]);
-      }
-      cnt += c;
-      if ((p.flags & VC_FLAG_USE_BITMAP) && (meta0[g] & 0xFFu) == 0 && idx0 + g < per_table) {
-        const uint32_t cls = (meta0[g] >> 16) & 0xFFu;
-#pragma unroll
-        for (uint32_t cc = 0; cc < MQ_MAX_GROUP; ++cc) hits0[cc] += cls == cc ? c : 0u;
-      }
-    }
-    for (;;) {   // append this pass's hits; what does not fit waits for a flush
-      if (__ballot(cnt != 0) == 0) break;
-      uint32_t wtot_v;
-      uint32_t pos = nh + vc_wave_excl_scan(cnt, wtot_v);
-      const uint32_t wtot = __builtin_amdgcn_readfirstlane(wtot_v);
-#pragma unroll
-      for (uint32_t g = 0; g < TP_G; ++g) {
-        const uint32_t qlo = qkey(meta0[g] & 0xFFu) & ((1u << LO) - 1u);
-#pragma unroll
-        for (uint32_t i = 0; i < GW; ++i)
-          while (w[g][i] && pos < TP_HM) {
-            const uint32_t bb = (uint32_t)__ffs((int)w[g][i]) - 1u;
-            w[g][i] &= w[g][i] - 1u;
-            const uint32_t xx = i * 32 + bb;
-            hkey[pos] = (gr[g] << LO) | xx;
-            hmeta[pos] = (meta0[g] & 0xFFu) | ((((meta0[g] >> 8) & 0xFFu) + __popc(xx ^ qlo)) << 8);
-            ++pos;
-            --cnt;
-          }
-      }
-      nh += wtot;
-      const uint32_t nh_now = nh;
-      if (nh_now >= TP_HFLUSH) flush();
-      if (nh_now <= TP_HM) break;            // everything fitted
+      atomicAdd(&p.phase_dbg[13], now - t_entry);
+      atomicAdd(&p.phase_dbg[21], 1ull);
+      atomicMin(&p.phase_dbg[24], t_entry);
+      atomicMax(&p.phase_dbg[30], now);
     }
   }
-  if (nh) flush();
-  uint32_t ent_tot;
-  (void)vc_wave_excl_scan(ent, ent_tot);
-  uint32_t h0[MQ_MAX_GROUP];
-#pragma unroll
-  for (uint32_t cc = 0; cc < MQ_MAX_GROUP; ++cc) (void)vc_wave_excl_scan(hits0[cc], h0[cc]);
-  if (lane == 0) {
-    uint32_t* head = p.bhead + (uint64_t)slot * 8;
-    head[0] = min(nb, TP_HCAP);
-    head[1] = ent_tot;
-    head[2] = h0[0];
-    head[3] = h0[1];
-    head[4] = h0[2];
-    head[5] = nb > TP_HCAP ? 1u : 0u;
-  }
-  tick(3);
-}
-
-static __host__ __device__ inline size_t tile_verify_lds(uint32_t buf_entries, uint32_t m, uint32_t W) {
-  return (size_t)buf_entries * 8 + (size_t)(3 * TV_H + 1) * 4 + (size_t)MQ_MAX_GROUP * mq_hist_bins(W) * 4 + 16 + (size_t)m * sizeof(VcTableView) + 16;
-}
-
-template <int W>
-__global__ void __launch_bounds__(MQ_BLK, TV_WAVES) mih_tile_verify_kernel(const TileParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* s_buf = (uint64_t*)smem;                         // [buf_entries] candidates, unsorted, tagged with their shell class
-  uint32_t* s_off = (uint32_t*)(s_buf + p.buf_entries);      // [TV_H] entry offset of the bucket
-  uint32_t* s_pref = s_off + TV_H;                           // [TV_H + 1] bucket length, then exclusive prefix
-  uint32_t* s_meta = s_pref + TV_H + 1;                      // [TV_H] table | substring distance << 8
-  const uint32_t HB = mq_hist_bins(W);
-  uint32_t* s_hist = s_meta + TV_H;                          // [MQ_MAX_GROUP][HB]
-  VcTableView* s_tv = (VcTableView*)(((uintptr_t)(s_hist + MQ_MAX_GROUP * HB) + 15) & ~(uintptr_t)15);   // [m]
-  __shared__ uint32_t s_ncand, s_seenc[MQ_MAX_GROUP], s_dk, s_wsum[MQ_BLK / VC_WAVE < 4 ? 4 : MQ_BLK / VC_WAVE];
-  __shared__ uint64_t s_thresh;
-
-  const uint32_t slot = blockIdx.x;
-  const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
-  const uint32_t m = p.m;
-  const uint32_t* head = p.bhead + (uint64_t)slot * 8;
-  __shared__ unsigned long long s_ph_last;
-  __shared__ uint32_t s_ph_cur;
-  auto tick = [&](uint32_t next) {   // ends the current phase, starts `next`
-    if (p.phase_dbg && tid == 0) {
-      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      atomicAdd(&p.phase_dbg[s_ph_cur], now - s_ph_last);
-      s_ph_last = now;
-      s_ph_cur = next;
-    }
-  };
-  if (p.phase_dbg && tid == 0) {
-    s_ph_last = __builtin_amdgcn_s_memrealtime();
-    s_ph_cur = 8;
-  }
-  const uint32_t nb = head[0];
-  if (head[5]) {                     // the bucket list outgrew its row: mih_query_kernel runs the query from shell 0
-    if (tid == 0) {
-      p.st.work[slot * 4 + 0] = 0;
-      p.st.work[slot * 4 + 1] = 0;
-      p.st.work[slot * 4 + 2] = 0;
-      p.cont_list[atomicAdd(p.cont_ctr, 1u)] = slot | MQ_SLOT_REDO;
-    }
-    return;
-  }
-  uint64_t qw[W];
-#pragma unroll
-  for (int j = 0; j < W; ++j) qw[j] = p.queries[(uint64_t)slot * W + j];
-  for (uint32_t i = tid; i < m * (sizeof(VcTableView) / 4); i += MQ_BLK) ((uint32_t*)s_tv)[i] = ((const uint32_t*)p.tables)[i];
-  for (uint32_t i = tid; i < MQ_MAX_GROUP * HB; i += MQ_BLK) s_hist[i] = 0;
-  if (tid < MQ_MAX_GROUP) s_seenc[tid] = 0;
-  if (tid == 0) {
-    s_ncand = 0;
-    s_thresh = VC_PACK_INF;
-  }
-  __syncthreads();
-
-  const uint4* const row = p.blist + (uint64_t)slot * TP_HCAP;
-  for (uint32_t c0 = 0; c0 < nb; c0 += TV_H) {
-    tick(9);
-    const uint32_t H = min(TV_H, nb - c0);
-    uint32_t lsum = 0, lv[TV_H / MQ_BLK];
-#pragma unroll
-    for (uint32_t i = 0; i < TV_H / MQ_BLK; ++i) {
-      const uint32_t idx = tid * (TV_H / MQ_BLK) + i;
-      lv[i] = 0;
-      if (idx < H) {
-        const uint4 e = row[c0 + idx];
-        s_off[idx] = e.x;
-        s_meta[idx] = e.z;
-        lv[i] = e.y;
-      }
-      lsum += lv[i];
-    }
-    uint32_t wtot;
-    uint32_t excl = vc_wave_excl_scan(lsum, wtot);
-    if (lane == 0) s_wsum[wave] = wtot;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < MQ_BLK / VC_WAVE; ++w) {
-      if (w < wave) wbase += s_wsum[w];
-      total += s_wsum[w];
-    }
-    excl += wbase;
-#pragma unroll
-    for (uint32_t i = 0; i < TV_H / MQ_BLK; ++i) {
-      const uint32_t idx = tid * (TV_H / MQ_BLK) + i;
-      if (idx < H) s_pref[idx] = excl;
-      excl += lv[i];
-    }
-    if (tid == 0) s_pref[H] = total;
-    __syncthreads();
-    tick(10);
-
-    uint32_t seen_acc = 0, seen_acc1 = 0, seen_acc2 = 0;   // per shell class (wave-uniform)
-    for (uint32_t e0 = 0; e0 < total; e0 += TV_ROUND) {
-      // room for one round of survivors (the fill is read between two barriers: see mih_query_kernel's drain)
-      __syncthreads();
-      const uint32_t fill = s_ncand;
-      __syncthreads();
-      if (fill + TV_ROUND > p.buf_entries) {
-        mq_compact(s_buf, &s_ncand, &s_thresh, s_wsum, p.buf_entries, MQ_MAX_GROUP, false);
-        if (s_ncand + TV_ROUND > p.buf_entries) mq_select_exact(s_buf, &s_ncand, &s_thresh, s_wsum, p.buf_entries, p.k);
-      }
-      const uint64_t thresh = s_thresh;
-      uint32_t local[TV_EPT], meta[TV_EPT];
-      uint64_t x[TV_EPT][W];
-      bool live[TV_EPT];
-#pragma unroll
-      for (uint32_t g = 0; g < TV_EPT; ++g) {
-        const uint32_t e = e0 + g * MQ_BLK + tid;
-        live[g] = e < total;
-        const uint32_t ec = live[g] ? e : 0;
-        uint32_t lo = 0, hi = H;               // largest b with s_pref[b] <= e
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_pref[mid] <= ec) lo = mid; else hi = mid;
-        }
-        meta[g] = s_meta[lo];
-        const VcTableView& tv = s_tv[meta[g] & 0xFFu];
-        const uint32_t pos = s_off[lo] + (ec - s_pref[lo]);
-        if (W <= 2 && tv.bent) {
-          const uint4 rec = tv.bent[(uint64_t)pos * W];
-          local[g] = rec.x;
-          x[g][0] = ((uint64_t)rec.w << 32) | rec.z;
-          if (W == 2) {
-            const uint4 rec1 = tv.bent[(uint64_t)pos * 2 + 1];
-            x[g][W - 1] = ((uint64_t)rec1.y << 32) | rec1.x;
-          }
-          continue;
-        }
-        local[g] = tv.ids[pos];
-        if (tv.bcodes) {
-#pragma unroll
-          for (int j = 0; j < W; ++j) x[g][j] = tv.bcodes[(uint64_t)j * p.n + pos];
-        } else {
-#pragma unroll
-          for (int j = 0; j < W; ++j) x[g][j] = p.cols[(uint64_t)j * p.stride + local[g]];
-        }
-      }
-#pragma unroll
-      for (uint32_t g = 0; g < TV_EPT; ++g) {
-        bool emit = live[g];
-        uint64_t packed = 0;
-        if (live[g]) {
-          const uint32_t t = meta[g] & 0xFFu, dt = meta[g] >> 8;
-          uint32_t dist = 0;
-          for (uint32_t tt = 0; tt < m; ++tt) {
-            const uint32_t bp = tt * 32u;
-            uint32_t field = 0;
-#pragma unroll
-            for (int j = 0; j < W; ++j)
-              if ((uint32_t)j == (bp >> 6)) field = (uint32_t)((x[g][j] ^ qw[j]) >> (bp & 63));
-            const uint32_t d = __popc(field);
-            dist += d;
-            // owner rule (see mih_probe_kernel): reported by the first table holding the minimum substring distance
-            if (tt != t && (d < dt || (d == dt && tt < t))) emit = false;
-          }
-          packed = vc_pack(dist, p.id_base + local[g]);
-        }
-        const uint64_t emask = __ballot(emit);
-        if (emask == 0) continue;
-        const uint32_t cls = meta[g] >> 8;   // shell class = substring distance (the pipeline starts at shell 0)
-        const uint64_t m1 = __ballot(emit && cls == 1), m2 = __ballot(emit && cls == 2);
-        seen_acc1 += (uint32_t)__popcll(m1);
-        seen_acc2 += (uint32_t)__popcll(m2);
-        seen_acc += (uint32_t)__popcll(emask & ~(m1 | m2));
-        const bool keep = emit && packed < thresh;
-        const uint64_t kmask = __ballot(keep);
-        if (kmask == 0) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&s_ncand, (uint32_t)__popcll(kmask));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (keep) {
-          s_buf[base + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull))] = packed | ((uint64_t)cls << MQ_TAG_SHIFT);
-          atomicAdd(&s_hist[cls * HB + (uint32_t)(packed >> 32)], 1u);
-        }
-      }
-    }
-    if (lane == 0 && seen_acc) atomicAdd(&s_seenc[0], seen_acc);
-    if (lane == 0 && seen_acc1) atomicAdd(&s_seenc[1], seen_acc1);
-    if (lane == 0 && seen_acc2) atomicAdd(&s_seenc[2], seen_acc2);
-    __syncthreads();
-  }
-
-  // ---- k-NN: sorted top-k of what the evaluated shells have seen -> s_buf[0 .. return value)  (mih_query_kernel's finish_sort)
-  auto finish_sort = [&](uint32_t max_cls) -> uint32_t {
-    mq_compact(s_buf, &s_ncand, &s_thresh, s_wsum, p.buf_entries, max_cls, true);
-    const uint32_t fill = s_ncand;
-    if (fill <= MQ_BLK) {
-      const uint64_t v = tid < fill ? s_buf[tid] : VC_PACK_INF;
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < fill; ++j) rank += s_buf[j] < v;
-      __syncthreads();
-      if (tid < fill) s_buf[rank] = v;
-      __syncthreads();
-      return min(fill, p.k);
-    }
-    uint32_t P = 2;
-    while (P < fill) P <<= 1;
-    for (uint32_t i = fill + tid; i < P; i += MQ_BLK) s_buf[i] = VC_PACK_INF;
-    vc_bitonic_lds(s_buf, P, MQ_BLK);
-    return min(fill, p.k);
-  };
-
-  // ---- the stop rule, shell by shell (mih_query_kernel's evaluation of a grouped pass)
-  tick(11);
-  unsigned long long sub = 0, loc = 0, w_probes = 0;
-  for (uint32_t rr = 0; rr < p.group; ++rr) {
-    if (rr) {
-      for (uint32_t i = tid; i < HB; i += MQ_BLK) {
-        s_hist[i] += s_hist[rr * HB + i];
-        s_hist[rr * HB + i] = 0;
-      }
-      if (tid == 0) {
-        s_seenc[0] += s_seenc[rr];
-        s_seenc[rr] = 0;
-      }
-      __syncthreads();
-    }
-    const unsigned long long leaves = c_binom[32][rr];
-    w_probes += leaves * m;
-    if (p.flags & VC_FLAG_USE_BITMAP) {
-      loc += leaves;
-      sub += head[2 + rr];
-    } else {
-      sub += leaves;
-    }
-    const uint32_t seen = s_seenc[0];
-    __syncthreads();
-    if (wave == 0) {
-      const uint32_t cut = seen >= p.k ? mw_hist_cut(s_hist, W * 64u + 1u, p.k) : 0xFFFFFFFFu;
-      if (lane == 0) s_dk = cut;
-    }
-    __syncthreads();
-    const uint32_t dk = s_dk;
-    bool stop;
-    if (p.mode == MQ_MODE_APPROX)
-      stop = seen >= p.k * MIH_APPROX_FACTOR;
-    else
-      stop = dk != 0xFFFFFFFFu && dk <= (rr + 1) * p.stop_mult;
-    if (tid == 0 && dk != 0xFFFFFFFFu) {
-      const uint64_t bnd = ((uint64_t)dk + 1) << 32;
-      if (bnd < s_thresh) s_thresh = bnd;
-    }
-    if (stop || rr == 32) {
-      tick(12);
-      const uint32_t kout = finish_sort(rr);
-      tick(13);
-      for (uint32_t i = tid; i < p.k; i += MQ_BLK) p.out[(uint64_t)slot * p.k + i] = i < kout ? s_buf[i] : VC_PACK_INF;
-      if (tid == 0) {
-        p.st.work[slot * 4 + 0] = w_probes;
-        p.st.work[slot * 4 + 1] = nb;
-        p.st.work[slot * 4 + 2] = head[1];
-        p.out_cnt[slot] = kout;
-        p.st.radius[slot] = rr;
-        p.st.seen[slot] = seen;
-        p.st.sub[slot] = sub;
-        p.st.loc[slot] = loc;
-        if (p.radius_hist) atomicAdd(&p.radius_hist[min(rr, 3u)], 1u);
-      }
-      tick(14);
-      return;
-    }
-    __syncthreads();
-  }
-  tick(12);
-  // not finished: state handed over as mih_commit_kernel leaves it -- to mih_query_kernel (resumes at shell `group`), or,
-  // when the one-block-per-query stage ends here, to the multi-block shells
-  const uint32_t kout = finish_sort(MQ_MAX_GROUP);
-  for (uint32_t i = tid; i < kout; i += MQ_BLK) p.st.topk[(uint64_t)slot * p.k + i] = s_buf[i];
-  if (tid == 0) {
-    p.st.work[slot * 4 + 0] = w_probes;
-    p.st.work[slot * 4 + 1] = nb;
-    p.st.work[slot * 4 + 2] = head[1];
-    p.st.count[slot] = kout;
-    p.st.prev[slot] = kout;
-    p.st.thresh[slot] = kout == p.k ? s_buf[p.k - 1] : VC_PACK_INF;
-    p.st.seen[slot] = s_seenc[0];
-    p.st.sub[slot] = sub;
-    p.st.loc[slot] = loc;
-    p.st.radius[slot] = 0;
-    p.st.topn[slot] = kout;
-    if (p.group - 1 < p.r_last) {
-      p.cont_list[atomicAdd(p.cont_ctr, 1u)] = slot;
-    } else {
-      p.heavy_list[atomicAdd(p.heavy_ctr, 1u)] = slot;
-      if (p.radius_hist) atomicAdd(&p.radius_hist[3], 1u);
-      const uint32_t r_end = kout == p.k ? min(32u, (uint32_t)(s_buf[p.k - 1] >> 32) / max(p.stop_mult, 1u)) : 32u;
-      unsigned long long pred = 0;
-      for (uint32_t r = p.r_last + 1; r <= r_end; ++r) pred += (unsigned long long)m * c_binom[32][r];
-      p.st.work[slot * 4 + 3] = pred;
-    }
-  }
-  tick(14);
 }
 
 // =============================================================================================================
@@ -2390,30 +1810,47 @@ __global__ void __launch_bounds__(256) mih_minsub_count_kernel(const uint64_t* _
 
 
 // sum the per-query work counters of one mih_query_kernel launch into the index-wide totals (vc_get_timing)
-__global__ void __launch_bounds__(256) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
+__global__ void __launch_bounds__(1024) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
                                                               unsigned long long* __restrict__ totals, const uint32_t* __restrict__ ctr,
-                                                              volatile uint32_t* __restrict__ host_ctr, const uint32_t* __restrict__ list,
-                                                              const uint32_t* __restrict__ list_count, uint32_t count_queries) {
-  if (list_count) nq = min(nq, *list_count);
+                                                              volatile uint32_t* __restrict__ host_ctr) {
   // the launch's counters (unfinished queries, where the others stopped) go straight to pinned host memory: the host
   // then only waits for the stream instead of queueing a copy behind it
   if (host_ctr && threadIdx.x < 6) host_ctr[2 + threadIdx.x] = ctr[2 + threadIdx.x];
   __shared__ unsigned long long s_t[3];
   if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
   __syncthreads();
+  // one memory round trip for a tile of 4096 queries: four 32-byte records per thread in flight (the serial form of
+  // this loop -- 256 threads, one record per iteration -- took 16 us behind every launch)
   unsigned long long a = 0, b = 0, c = 0;
-  for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) {
-    const uint32_t i = list ? (list[j] & ~MQ_SLOT_REDO) : j;
-    a += work[i * 4 + 0];
-    b += work[i * 4 + 1];
-    c += work[i * 4 + 2];
+  const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(work);
+  for (uint32_t base = 0; base < nq; base += 4 * blockDim.x) {
+    ulonglong2 v0[4], v1[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t i = base + u * blockDim.x + threadIdx.x;
+      v0[u] = i < nq ? w2[(size_t)i * 2] : make_ulonglong2(0, 0);
+      v1[u] = i < nq ? w2[(size_t)i * 2 + 1] : make_ulonglong2(0, 0);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      a += v0[u].x;
+      b += v0[u].y;
+      c += v1[u].x;
+    }
   }
-  atomicAdd(&s_t[0], a);
-  atomicAdd(&s_t[1], b);
-  atomicAdd(&s_t[2], c);
+  for (uint32_t o = VC_WAVE / 2; o; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+    c += __shfl_xor(c, o);
+  }
+  if (vc_lane() == 0) {
+    atomicAdd(&s_t[0], a);
+    atomicAdd(&s_t[1], b);
+    atomicAdd(&s_t[2], c);
+  }
   __syncthreads();
   if (threadIdx.x < 3) totals[threadIdx.x] += s_t[threadIdx.x];
-  if (threadIdx.x == 3 && count_queries) totals[3] += nq;
+  if (threadIdx.x == 3) totals[3] += nq;
 }
 
 // per-query result segments of the radius search: ring[q][0 .. min(count, cap)) sorted ascending in place.
@@ -2551,9 +1988,6 @@ struct VcMihIndex {
   size_t ring_entries = 0;
   size_t lds_per_block = 65536;             // hipDeviceProp.sharedMemPerBlock of the index's device
   uint32_t group_hint = 2;                  // shells grouped into the query kernel's first pass (adapts to where queries stop)
-  // tile pipeline (mih_tile_*_kernel; lazy): per-query bucket rows, their heads, the list of queries mih_query_kernel continues
-  uint4* d_blist = nullptr;                 // [MIH_QTILE][TP_HCAP]
-  uint32_t* d_bhead = nullptr;              // [MIH_QTILE][8] | [MIH_QTILE] continuation list
 };
 
 #define MIH_CHECK(call)                                                                                  \
@@ -2599,8 +2033,6 @@ void vc_mih_free(VcMihIndex* ix) {
   for (auto& pr : ix->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   (void)hipFree(ix->d_totals);
   (void)hipFree(ix->d_ring);
-  (void)hipFree(ix->d_blist);
-  (void)hipFree(ix->d_bhead);
   delete ix;
 }
 
@@ -3185,36 +2617,16 @@ static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, ui
   return hipGetLastError();
 }
 
-static hipError_t launch_tile_kernels(const TileParams& tp, uint32_t W, hipStream_t s) {
-  const size_t lds_p = tp_shared_bytes(tp.m) + (size_t)4 * tp_wave_words(tp.m, TP_LO) * 4;
-  const size_t lds_v = tile_verify_lds(tp.buf_entries, tp.m, W);
-  const dim3 grid_p((tp.nq + 3) / 4), grid_v(tp.nq);
-#define TP_LAUNCH(W_)                                                                                          \
-  case W_:                                                                                                     \
-    hipLaunchKernelGGL((mih_tile_probe_kernel<W_, TP_LO>), grid_p, dim3(256), lds_p, s, tp);                   \
-    hipLaunchKernelGGL((mih_tile_verify_kernel<W_>), grid_v, dim3(MQ_BLK), lds_v, s, tp);                      \
-    break;
-  switch (W) {
-    TP_LAUNCH(1)
-    TP_LAUNCH(2)
-    TP_LAUNCH(4)
-    TP_LAUNCH(8)
-    default: return hipErrorInvalidValue;
-  }
-#undef TP_LAUNCH
-  return hipGetLastError();
-}
-
-// launch + measurement: events on the launch stream around the kernel, then the reduction of its work counters.
-// `tile`: the batch goes through the tile pipeline first (probe + verify stage, inside the same pair of events), and
-// mih_query_kernel serves the continuation list those leave (p_in.slot_list / slot_count / r_first set by the caller).
-static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_in, uint32_t W, uint32_t nq, hipStream_t s,
-                                     const TileParams* tile = nullptr) {
+// launch + measurement: events on the launch stream around the kernel, then the reduction of its work counters
+static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_in, uint32_t W, uint32_t nq, hipStream_t s) {
   QueryKernelParams p = p_in;
   static unsigned long long* d_phase = nullptr;   // dev knob VC_MIH_PHASES: one buffer per process is enough
   if (ix->knobs.mih_phases && p.mode != MQ_MODE_RADIUS) {
-    if (!d_phase && hipMalloc((void**)&d_phase, 64) != hipSuccess) d_phase = nullptr;
-    if (d_phase) (void)hipMemsetAsync(d_phase, 0, 64, s);
+    if (!d_phase && hipMalloc((void**)&d_phase, 256) != hipSuccess) d_phase = nullptr;
+    if (d_phase) {
+      (void)hipMemsetAsync(d_phase, 0, 256, s);
+      (void)hipMemsetAsync(d_phase + 24, 0xFF, 8, s);
+    }
     p.phase_dbg = d_phase;
   }
   if (!ix->d_totals) {
@@ -3233,40 +2645,22 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
     if (ix->ev_used < ix->ev_pool.size()) ev = &ix->ev_pool[ix->ev_used++];
   }
   if (ev) (void)hipEventRecord(ev->first, s);
-  hipError_t r = hipSuccess;
-  static unsigned long long* d_tphase = nullptr;
-  if (tile) {
-    TileParams tp = *tile;
-    if (ix->knobs.mih_phases) {
-      if (!d_tphase && hipMalloc((void**)&d_tphase, 128) != hipSuccess) d_tphase = nullptr;
-      if (d_tphase) (void)hipMemsetAsync(d_tphase, 0, 128, s);
-      tp.phase_dbg = d_tphase;
-    }
-    r = launch_tile_kernels(tp, W, s);
-    if (r != hipSuccess) return r;
-    // the pipeline's own work counters (every query of the batch); the continuation below adds its part through the list
-    hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(256), 0, s, p.st.work, nq, ix->d_totals, (const uint32_t*)nullptr,
-                       (volatile uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u);
-  }
-  r = launch_query_kernel(p, W, nq, s);
+  hipError_t r = launch_query_kernel(p, W, nq, s);
   if (ev) (void)hipEventRecord(ev->second, s);
   if (r != hipSuccess) return r;
   // (k-NN launches only: heavy_ctr = the tile's counter block + 2; radius search has no counters to publish)
-  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(256), 0, s, p.st.work, nq, ix->d_totals,
+  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(1024), 0, s, p.st.work, nq, ix->d_totals,
                      p.heavy_ctr ? (const uint32_t*)p.heavy_ctr - 2 : (const uint32_t*)nullptr,
-                     p.heavy_ctr ? (volatile uint32_t*)ix->h_ctr_dev : (volatile uint32_t*)nullptr, p.slot_list, p.slot_count,
-                     p.slot_list ? 0u : 1u);
-  if (tile && ix->knobs.mih_phases && d_tphase) {
-    unsigned long long h[16];
-    if (hipMemcpyAsync(h, d_tphase, 128, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
-      fprintf(stderr, "[vc_mih tile phases] %u queries, us per query: probe stage set-up %.1f | scan %.1f | directory %.1f | head %.1f || verify stage set-up %.1f | list %.1f | verify %.1f | evaluate %.1f | finish %.1f | out %.1f\n",
-              nq, h[0] * 0.01 / nq, h[1] * 0.01 / nq, h[2] * 0.01 / nq, h[3] * 0.01 / nq, h[8] * 0.01 / nq, h[9] * 0.01 / nq, h[10] * 0.01 / nq,
-              h[11] * 0.01 / nq, h[12] * 0.01 / nq, h[13] * 0.01 / nq);
-  }
+                     p.heavy_ctr ? (volatile uint32_t*)ix->h_ctr_dev : (volatile uint32_t*)nullptr);
   if (p.phase_dbg) {
-    unsigned long long h[8];
-    if (hipMemcpyAsync(h, p.phase_dbg, 64, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
-      fprintf(stderr, "[vc_mih phases] %u blocks, us per block: set-up %.1f | plan+scan %.1f | directory %.1f | verify %.1f | evaluate %.1f | finish %.1f | out %.1f\n", nq,
+    unsigned long long h[32];
+    if (hipMemcpyAsync(h, p.phase_dbg, 256, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+      fprintf(stderr, "[vc_mih lifetimes] stop shell: blocks, mean lifetime us, last end (us after the first block's start):");
+      for (int c = 0; c < 6; ++c)
+        if (h[16 + c]) fprintf(stderr, "  %s%d: %llu, %.1f, %.1f", c == 5 ? "handed over after " : "", c == 5 ? (int)p.r_last : c, h[16 + c], h[8 + c] * 0.01 / h[16 + c], (h[25 + c] - h[24]) * 0.01);
+      fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "[vc_mih phases] %u blocks, us per block: set-up %.1f | plan+scan %.1f | directory %.1f | verify %.1f | evaluate %.1f | finish %.1f | out %.1f\n", nq,
               (h[7] + h[0]) * 0.01 / nq, h[1] * 0.01 / nq, h[2] * 0.01 / nq, h[3] * 0.01 / nq, h[4] * 0.01 / nq, h[5] * 0.01 / nq, h[6] * 0.01 / nq);
   }
   return hipGetLastError();
@@ -3404,17 +2798,6 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   // most of them needed (at most 3; VC_MIH_GROUP fixes it).
   uint32_t group = ix->knobs.mih_group > 0 ? (uint32_t)ix->knobs.mih_group : ix->group_hint;
   group = std::max(1u, std::min(group, std::min(3u, r_last + 1)));
-  // Batches of 32-bit-substring queries run shells 0 .. group-1 through the tile pipeline (mih_tile_probe_kernel ->
-  // mih_tile_verify_kernel), mih_query_kernel behind them for what is left; VC_MIH_TILE=0 keeps everything in
-  // mih_query_kernel, =2 sends every batch through the pipeline (tests)
-  uint32_t vbuf = 1024;
-  while (vbuf < MQ_MAX_GROUP * k + TV_ROUND) vbuf <<= 1;
-  const bool tile_ok = inblock && S == 32 && ix->knobs.mih_tile != 0 && ix->m <= 16 && vbuf <= 4096 &&
-                       tile_verify_lds(vbuf, ix->m, ix->W) <= ix->lds_per_block;
-  if (tile_ok && !ix->d_blist) {
-    MIH_CHECK(hipMalloc((void**)&ix->d_blist, (size_t)MIH_QTILE * TP_HCAP * sizeof(uint4)));
-    MIH_CHECK(hipMalloc((void**)&ix->d_bhead, (size_t)MIH_QTILE * 9 * 4));
-  }
 
   for (uint32_t q0 = 0; q0 < nq; q0 += MIH_QTILE) {
     const uint32_t qt = std::min(MIH_QTILE, nq - q0);
@@ -3429,18 +2812,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0; qp.group = group; qp.radius_hist = d_ctr + 4;
       const auto t_q = std::chrono::steady_clock::now();
       MIH_CHECK(hipMemsetAsync(d_ctr, 0, 32, s));
-      if (tile_ok && (qt >= 512 || ix->knobs.mih_tile == 2)) {
-        TileParams tp{};
-        tp.cols = d_cols; tp.stride = stride; tp.n = ix->n; tp.tables = ix->d_tables; tp.queries = qp.queries; tp.st = st;
-        tp.nq = qt; tp.m = ix->m; tp.id_base = ix->id_base; tp.flags = ix->flags; tp.k = k; tp.mode = qp.mode;
-        tp.stop_mult = stop_mult; tp.group = group; tp.r_last = r_last; tp.buf_entries = vbuf;
-        tp.blist = ix->d_blist; tp.bhead = ix->d_bhead; tp.cont_list = ix->d_bhead + (size_t)MIH_QTILE * 8; tp.cont_ctr = d_ctr + 3;
-        tp.heavy_list = cur; tp.heavy_ctr = d_ctr + 2; tp.out = qp.out; tp.out_cnt = qp.out_cnt; tp.radius_hist = d_ctr + 4;
-        qp.slot_list = tp.cont_list; qp.slot_count = tp.cont_ctr; qp.r_first = group;
-        MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s, &tp));
-      } else {
-        MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
-      }
+      MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
       if (!ix->h_ctr_dev) MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 24, hipMemcpyDeviceToHost, s));   // (else published by the reduce kernel)
       MIH_CHECK(hipStreamSynchronize(s));   // unfinished queries + where the others stopped
       n_heavy = n_cur = h_ctr[2];
@@ -3448,8 +2820,8 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
         ix->group_hint = (uint64_t)(h_ctr[6] + h_ctr[7]) * 10 >= (uint64_t)qt * 6 ? 3u : 2u;
       r_start = r_last + 1;
       if (trace)
-        fprintf(stderr, "[vc_mih] shells 0..%u in the query kernels (group %u): %u queries, %u continue, %u through the continuation list, stopped in shell 0/1/2/later %u/%u/%u/%u  %.1f us\n",
-                r_last, group, qt, n_cur, h_ctr[3], h_ctr[4], h_ctr[5], h_ctr[6], h_ctr[7],
+        fprintf(stderr, "[vc_mih] shells 0..%u in the query kernel (group %u): %u queries, %u continue, stopped in shell 0/1/2/later %u/%u/%u/%u  %.1f us\n",
+                r_last, group, qt, n_cur, h_ctr[4], h_ctr[5], h_ctr[6], h_ctr[7],
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_q).count());
       if (n_heavy) {
         MIH_CHECK(hipMemcpyAsync(lists[3], cur, (size_t)n_heavy * 4, hipMemcpyDeviceToDevice, s));
