@@ -781,7 +781,10 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   constexpr uint32_t MQ_HI = 32u - MQ_LO;
   constexpr uint32_t MQ_GW = (1u << MQ_LO) / 32u;                    // 32-bit words per granule
   constexpr uint32_t MQ_NJ = MQ_LO + 1u;                              // masks per table: j = 0 .. LO flips inside the low part
-  constexpr uint32_t MQ_G32 = MQ_GW >= 16u ? 1u : 16u / MQ_GW;        // granules per thread per pass (64 bytes in flight per lane)
+#ifndef MQ_GPT_KNN
+#define MQ_GPT_KNN 4u
+#endif
+  constexpr uint32_t MQ_G32 = MQ_GW >= 16u ? 1u : (MQ_GW == 4u ? MQ_GPT_KNN : 16u / MQ_GW);   // granules per thread per pass (64 bytes in flight per lane)
   constexpr uint32_t MQ_PASS32 = MQ_BLK * MQ_G32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* s_buf = (uint64_t*)smem;                         // [buf_entries] top-k (sorted) | fresh candidates
