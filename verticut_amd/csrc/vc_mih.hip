@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   constexpr uint32_t MQ_GW = (1u << MQ_LO) / 32u;                    // 32-bit words per granule
   constexpr uint32_t MQ_NJ = MQ_LO + 1u;                              // masks per table: j = 0 .. LO flips inside the low part
 #ifndef MQ_GPT_KNN
-#define MQ_GPT_KNN 4u
+#define MQ_GPT_KNN 6u
 #endif
   constexpr uint32_t MQ_G32 = MQ_GW >= 16u ? 1u : (MQ_GW == 4u ? MQ_GPT_KNN : 16u / MQ_GW);   // granules per thread per pass (64 bytes in flight per lane)
   constexpr uint32_t MQ_PASS32 = MQ_BLK * MQ_G32;
@@ -814,7 +814,8 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     asm volatile("" : "+s"(q));   // opaque: the loads stay behind this point
     return q;
   };
-  const unsigned long long t_entry = p.phase_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  __shared__ unsigned long long s_t_entry;   // dev (VC_MIH_PHASES): thread 0's clock at entry -- in LDS, not in a register pair that lives to the end
+  if (p.phase_dbg && threadIdx.x == 0) s_t_entry = __builtin_amdgcn_s_memrealtime();
 
   uint64_t qw[W];
 #pragma unroll
@@ -882,7 +883,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   if (p.phase_dbg && tid == 0) {
     s_ph_last = __builtin_amdgcn_s_memrealtime();
     s_ph_cur = 0;
-    atomicAdd(&p.phase_dbg[7], s_ph_last - t_entry);   // set-up: query, tables, binomials, masks
+    atomicAdd(&p.phase_dbg[7], s_ph_last - s_t_entry);   // set-up: query, tables, binomials, masks
   }
   uint32_t r_base = 0;             // first shell of the current pass: a candidate's class = its substring distance - r_base (block-uniform)
   uint32_t kk = 0;                 // radius mode: sorted results in s_buf[0..kk)           (block-uniform)
@@ -1147,11 +1148,11 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         hi = mq_unrank(s_binom, rem - s_segstart[seg], s_segh[seg], MQ_HI);
       }
       uint4 v[MQ_G32][MQ_GW / 4];
-      uint32_t gr[MQ_G32], meta0[MQ_G32], mi[MQ_G32], qlo[MQ_G32];   // meta0 = table | |hi| << 8
+      uint32_t gr[MQ_G32], meta0[MQ_G32];   // meta0 = table | |hi| << 8 | mask index << 16 | shell class << 30
 #pragma unroll
       for (uint32_t g = 0; g < MQ_G32; ++g) {
         const uint32_t idx = idx0 + g;
-        gr[g] = 0; meta0[g] = 0; mi[g] = 0; qlo[g] = 0;
+        gr[g] = 0; meta0[g] = 0;
 #pragma unroll
         for (uint32_t c = 0; c < MQ_GW / 4; ++c) v[g][c] = make_uint4(0, 0, 0, 0);
         if (idx < total) {
@@ -1169,21 +1170,18 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
               hi = vc_next_comb(hi);
             }
           }
-          const uint32_t qk = qkey(t);
-          gr[g] = (qk >> MQ_LO) ^ hi;
-          qlo[g] = qk & ((1u << MQ_LO) - 1u);
-          meta0[g] = t | (s_segh[seg] << 8) | ((s_segr[seg] - r_base) << 30);   // bits 30..31: shell class of the segment
-          mi[g] = t * MQ_NJ + s_segmask[seg];
+          gr[g] = (qkey(t) >> MQ_LO) ^ hi;
+          meta0[g] = t | (s_segh[seg] << 8) | (s_segmask[seg] << 16) | ((s_segr[seg] - r_base) << 30);   // bits 30..31: shell class of the segment
           const uint4* gp = reinterpret_cast<const uint4*>(s_tv[t].bitmap + (uint64_t)gr[g] * MQ_GW);
 #pragma unroll
           for (uint32_t c = 0; c < MQ_GW / 4; ++c) v[g][c] = gp[c];
         }
       }
       uint32_t w[MQ_G32][MQ_GW];
-      uint32_t cnt = 0, cnt0[MQ_MAX_GROUP] = {0, 0, 0};
+      uint32_t cnt = 0;
 #pragma unroll
       for (uint32_t g = 0; g < MQ_G32; ++g) {
-        const uint32_t* mk = s_mask + mi[g] * MQ_GW;
+        const uint32_t* mk = s_mask + ((meta0[g] & 0xFFu) * MQ_NJ + ((meta0[g] >> 16) & 0xFu)) * MQ_GW;
         uint32_t c = 0;
 #pragma unroll
         for (uint32_t cc = 0; cc < MQ_GW / 4; ++cc) {
@@ -1194,12 +1192,18 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           c += __popc(w[g][4 * cc + 0]) + __popc(w[g][4 * cc + 1]) + __popc(w[g][4 * cc + 2]) + __popc(w[g][4 * cc + 3]);
         }
         cnt += c;
-        if ((meta0[g] & 0xFFu) == 0 && tb_first == 0 && idx0 + g < per_table) {
-#pragma unroll
-          for (uint32_t cc = 0; cc < MQ_MAX_GROUP; ++cc) cnt0[cc] += (meta0[g] >> 30) == cc ? c : 0u;
-        }
       }
       if (p.flags & VC_FLAG_USE_BITMAP) {   // n_sub_reads_ of table 0 = its leaves whose bit is set (search_worker.cc:238-245)
+        uint32_t cnt0[MQ_MAX_GROUP] = {0, 0, 0};   // (counted here, not in the loop above: three registers fewer while the granules are in flight)
+#pragma unroll
+        for (uint32_t g = 0; g < MQ_G32; ++g)
+          if ((meta0[g] & 0xFFu) == 0 && tb_first == 0 && idx0 + g < per_table) {
+            uint32_t c = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < MQ_GW; ++i) c += __popc(w[g][i]);
+#pragma unroll
+            for (uint32_t cc = 0; cc < MQ_MAX_GROUP; ++cc) cnt0[cc] += (meta0[g] >> 30) == cc ? c : 0u;
+          }
 #pragma unroll
         for (uint32_t cc = 0; cc < MQ_MAX_GROUP; ++cc) {
           uint32_t wt;
@@ -1215,7 +1219,8 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         if (lane == 0 && wtot) wb = atomicAdd(&s_nh, wtot);
         uint32_t pos = __builtin_amdgcn_readfirstlane(wb) + off;
 #pragma unroll
-        for (uint32_t g = 0; g < MQ_G32; ++g)
+        for (uint32_t g = 0; g < MQ_G32; ++g) {
+          const uint32_t qlo = qkey(meta0[g] & 0xFFu) & ((1u << MQ_LO) - 1u);
 #pragma unroll
           for (uint32_t i = 0; i < MQ_GW; ++i)
             while (w[g][i] && pos < MQ_HMAX) {
@@ -1223,10 +1228,11 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
               w[g][i] &= w[g][i] - 1u;
               const uint32_t x = i * 32 + bb;
               s_key[pos] = (gr[g] << MQ_LO) | x;
-              s_meta[pos] = (meta0[g] & 0xFFFFu) + (__popc(x ^ qlo[g]) << 8);
+              s_meta[pos] = (meta0[g] & 0xFFFFu) + (__popc(x ^ qlo) << 8);
               ++pos;
               --cnt;
             }
+        }
         __syncthreads();
         const uint32_t nh = s_nh;
         if (nh >= MQ_HFLUSH) drain();
@@ -1458,9 +1464,9 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         tick(6);
         if (p.phase_dbg && tid == 0) {
           const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-          atomicAdd(&p.phase_dbg[8 + min(rr, 4u)], now - t_entry);
+          atomicAdd(&p.phase_dbg[8 + min(rr, 4u)], now - s_t_entry);
           atomicAdd(&p.phase_dbg[16 + min(rr, 4u)], 1ull);
-          atomicMin(&p.phase_dbg[24], t_entry);
+          atomicMin(&p.phase_dbg[24], s_t_entry);
           atomicMax(&p.phase_dbg[25 + min(rr, 4u)], now);
         }
         return;
@@ -1499,9 +1505,9 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     cold()->st.work[slot * 4 + 3] = pred;
     if (p.phase_dbg) {
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      atomicAdd(&p.phase_dbg[13], now - t_entry);
+      atomicAdd(&p.phase_dbg[13], now - s_t_entry);
       atomicAdd(&p.phase_dbg[21], 1ull);
-      atomicMin(&p.phase_dbg[24], t_entry);
+      atomicMin(&p.phase_dbg[24], s_t_entry);
       atomicMax(&p.phase_dbg[30], now);
     }
   }
