@@ -37,3 +37,22 @@ template __global__ void vc_scan_kernel<2>(const unsigned*, unsigned*, unsigned)
     assert any(v["private_segment_fixed_size"] > 0 for v in res.values())
     with pytest.raises(RuntimeError, match="scratch"):
         vb.check_scan_code_objects(str(obj))
+
+
+def test_shipped_query_kernels_of_the_configs_shapes_have_no_scratch(vc):
+    """mih_query_kernel for 64- and 128-bit codes (BASELINE configs[1] and the exact / approximate k-NN of configs[2]) is
+    compiled for 4 waves per SIMD and sits at the 128-VGPR limit: a change that tips it over shows up
+    here as scratch, not as a slower bench line three steps later.  SGPR spills (to VGPR lanes) are bounded, not zero."""
+    from verticut_amd import build as vb
+    obj = os.path.join(vb.LIBDIR, "vc_mih.o")
+    if not os.path.exists(obj):
+        vb.build(force=True)
+    res = {k: v for k, v in vb.kernel_resources(obj).items() if "mih_query_kernel" in k}
+    assert len(res) == 8                              # W = 1, 2, 4, 8 x the two granule widths
+    narrow = {k: v for k, v in res.items() if "ILi1E" in k or "ILi2E" in k}
+    assert len(narrow) == 4
+    for k, v in narrow.items():
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
+        assert v["vgpr_count"] <= 128 and v["sgpr_spill_count"] <= 80, (k, v)
+    stream = {k: v for k, v in vb.kernel_resources(obj).items() if "mih_bucket_stream_kernel" in k}
+    assert stream and all(v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 for v in stream.values())
