@@ -21,6 +21,7 @@
 // ============================================================================
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -1820,11 +1821,19 @@ __global__ void __launch_bounds__(256) mih_minsub_count_kernel(const uint64_t* _
 
 // sum the per-query work counters of one mih_query_kernel launch into the index-wide totals (vc_get_timing)
 __global__ void __launch_bounds__(1024) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
-                                                              unsigned long long* __restrict__ totals, const uint32_t* __restrict__ ctr,
-                                                              volatile uint32_t* __restrict__ host_ctr) {
-  // the launch's counters (unfinished queries, where the others stopped) go straight to pinned host memory: the host
-  // then only waits for the stream instead of queueing a copy behind it
-  if (host_ctr && threadIdx.x < 6) host_ctr[2 + threadIdx.x] = ctr[2 + threadIdx.x];
+                                                              unsigned long long* __restrict__ totals, uint32_t* __restrict__ ctr,
+                                                              volatile uint32_t* __restrict__ host_ctr, uint32_t seq) {
+  // the launch's counters (unfinished queries, where the others stopped) go straight to pinned host memory, followed by the
+  // launch's sequence number: the host polls that word instead of queueing a copy and waiting for the stream (every query
+  // kernel block has exited when this kernel runs, so the counters are final)
+  if (host_ctr && threadIdx.x == 0) {
+    for (uint32_t i = 2; i < 8; ++i) {
+      host_ctr[i] = ctr[i];
+      ctr[i] = 0;                        // ready for the next launch: no memset in front of it
+    }
+    __threadfence_system();
+    host_ctr[8] = seq;
+  }
   __shared__ unsigned long long s_t[3];
   if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
   __syncthreads();
@@ -1989,6 +1998,7 @@ struct VcMihIndex {
   uint32_t* d_lists = nullptr;   // 3 * MIH_QTILE + 4 counters
   uint32_t* h_ctr = nullptr;     // pinned: the counters the host reads back after every launch sequence
   uint32_t* h_ctr_dev = nullptr; // its device-side alias (mapped): the query kernel's counters are stored there directly
+  uint32_t ctr_seq = 0;          // sequence number of the last counter publication (h_ctr[8] when it has landed)
   // measurement (vc_get_timing): event pairs around every mih_query_kernel launch, device totals of its work counters
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -2573,7 +2583,10 @@ static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, bool with_ring,
     MIH_CHECK(hipMalloc((void**)&ix->d_ring, Q * cap * 8));
     ix->ring_entries = Q * cap;
   }
-  if (!ix->d_lists) MIH_CHECK(hipMalloc((void**)&ix->d_lists, (4 * Q + 8) * 4));   // 4 slot lists + 4 counters + 4 stop-shell counts
+  if (!ix->d_lists) {   // 4 slot lists + 4 counters + 4 stop-shell counts (the counters start at zero; the reduce kernel re-zeroes what a launch counted)
+    MIH_CHECK(hipMalloc((void**)&ix->d_lists, (4 * Q + 8) * 4));
+    MIH_CHECK(hipMemset(ix->d_lists + 4 * Q, 0, 32));
+  }
   uint8_t* b = (uint8_t*)ix->d_tile;
   st->thresh = (uint64_t*)(b + o_thresh);
   st->ring = ix->d_ring;
@@ -2659,8 +2672,8 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
   if (r != hipSuccess) return r;
   // (k-NN launches only: heavy_ctr = the tile's counter block + 2; radius search has no counters to publish)
   hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(1024), 0, s, p.st.work, nq, ix->d_totals,
-                     p.heavy_ctr ? (const uint32_t*)p.heavy_ctr - 2 : (const uint32_t*)nullptr,
-                     p.heavy_ctr ? (volatile uint32_t*)ix->h_ctr_dev : (volatile uint32_t*)nullptr);
+                     p.heavy_ctr ? p.heavy_ctr - 2 : (uint32_t*)nullptr,
+                     p.heavy_ctr ? (volatile uint32_t*)ix->h_ctr_dev : (volatile uint32_t*)nullptr, ++ix->ctr_seq);
   if (p.phase_dbg) {
     unsigned long long h[32];
     if (hipMemcpyAsync(h, p.phase_dbg, 256, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
@@ -2772,7 +2785,8 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   const uint32_t stop_mult = (ix->flags & VC_FLAG_REF_STOP_LITERAL4) ? 4u : std::min(ix->m, 4u);
   MihState st;
   if (!ix->h_ctr) {
-    MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 32, hipHostMallocMapped));
+    MIH_CHECK(hipHostMalloc((void**)&ix->h_ctr, 64, hipHostMallocMapped));
+    ix->h_ctr[8] = 0;
     if (hipHostGetDevicePointer((void**)&ix->h_ctr_dev, ix->h_ctr, 0) != hipSuccess) { (void)hipGetLastError(); ix->h_ctr_dev = nullptr; }
   }   // pageable memory makes the read-back a staged copy
   uint32_t* h_ctr = ix->h_ctr;
@@ -2820,10 +2834,20 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       qp.buf_entries = buf_entries; qp.heavy_list = cur; qp.heavy_ctr = d_ctr + 2;
       qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0; qp.group = group; qp.radius_hist = d_ctr + 4;
       const auto t_q = std::chrono::steady_clock::now();
-      MIH_CHECK(hipMemsetAsync(d_ctr, 0, 32, s));
+      if (!ix->h_ctr_dev) MIH_CHECK(hipMemsetAsync(d_ctr, 0, 32, s));   // (else zeroed at allocation and by every reduce kernel since)
       MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
-      if (!ix->h_ctr_dev) MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 24, hipMemcpyDeviceToHost, s));   // (else published by the reduce kernel)
-      MIH_CHECK(hipStreamSynchronize(s));   // unfinished queries + where the others stopped
+      // unfinished queries + where the others stopped: published by the reduce kernel into mapped host memory, sequence
+      // number last; polling that word returns ~10 us before hipStreamSynchronize does (VC_MIH_POLL=0: plain synchronise)
+      bool landed = false;
+      if (ix->h_ctr_dev && ix->knobs.mih_poll) {
+        volatile uint32_t* flag = h_ctr + 8;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; !(landed = (*flag == ix->ctr_seq)); ++spins)
+          if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;   // long launches (or a fault): wait properly
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
+      if (!ix->h_ctr_dev) MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 24, hipMemcpyDeviceToHost, s));
+      if (!landed) MIH_CHECK(hipStreamSynchronize(s));
       n_heavy = n_cur = h_ctr[2];
       if (S == 32 && qt >= 64)       // next launch: group up to shell 2 when most queries of this one needed it
         ix->group_hint = (uint64_t)(h_ctr[6] + h_ctr[7]) * 10 >= (uint64_t)qt * 6 ? 3u : 2u;
