@@ -199,8 +199,9 @@ int vc_search_radius(vc_engine* e, const void* queries, uint32_t nq, uint32_t ra
                      uint64_t* out, uint64_t out_cap, uint64_t* out_offsets);
 
 /* Device-pointer variant (queries and results stay in HBM): d_queries nq*bits/8 bytes, d_out out_cap packed values,
- * d_offsets nq+1 entries, all device memory.  The work is enqueued on `stream`; the host synchronises that stream once,
- * at the end, to learn the total (and repeats the call internally with a larger work ring if a query outgrew it).
+ * d_offsets nq+1 entries, all device memory.  The work is enqueued on `stream`; the host waits once, at the end, for the
+ * total (and repeats the call internally with a larger work ring if a query outgrew it).  The copy into d_out may still be
+ * running on `stream` when the call returns: the results are valid in stream order, a host reader copies behind it.
  * VC_ERR_CAPACITY if the results do not fit out_cap (d_offsets then holds the needed counts).
  * replaces: the same reference loop as vc_search_radius (search_worker.cc:222-264). */
 int vc_search_radius_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t radius, uint32_t mode,

@@ -1898,7 +1898,8 @@ __global__ void __launch_bounds__(1024) vc_sort_segments_kernel(uint64_t* __rest
 // exclusive prefix of one tile's segment lengths behind the running total of the call:
 // offsets[i] = tot[0] + sum_{j<i} count[j];  tot[0] += sum;  tot[1] = max(tot[1], max count)  (overflow detection)
 __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t* __restrict__ count, uint32_t nq,
-                                                                 uint64_t* __restrict__ offsets, unsigned long long* tot) {
+                                                                 uint64_t* __restrict__ offsets, unsigned long long* tot,
+                                                                 volatile unsigned long long* host_tot, unsigned long long seq) {
   __shared__ uint64_t s_w[1024 / VC_WAVE];
   __shared__ uint32_t s_max;
   const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
@@ -1935,6 +1936,12 @@ __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t*
     offsets[nq] = tot[0] + total;
     tot[0] += total;
     if (s_max > tot[1]) tot[1] = s_max;
+    if (host_tot && seq) {   // last tile of a call: total and largest segment go to mapped host memory, the call's sequence number last
+      host_tot[0] = tot[0];
+      host_tot[1] = tot[1];
+      __threadfence_system();
+      host_tot[2] = seq;
+    }
   }
 }
 
@@ -3054,7 +3061,12 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
     R_CHECK(hipMalloc((void**)&wk->d_aux, aux_words * 4));
     wk->aux_words = aux_words;
   }
-  if (!wk->h_tot) R_CHECK(hipHostMalloc((void**)&wk->h_tot, 16, hipHostMallocDefault));
+  if (!wk->h_tot) {
+    R_CHECK(hipHostMalloc((void**)&wk->h_tot, 32, hipHostMallocMapped));
+    wk->h_tot[2] = 0;
+    if (hipHostGetDevicePointer((void**)&wk->h_tot_dev, wk->h_tot, 0) != hipSuccess) { (void)hipGetLastError(); wk->h_tot_dev = nullptr; }
+  }
+  const bool poll = wk->h_tot_dev && (!knobs || knobs->mih_poll);
   uint32_t* d_count = wk->d_aux;
   uint32_t* d_tau = wk->d_aux + TQ;
   uint32_t* d_sorted = wk->d_aux + 2 * TQ;
@@ -3126,13 +3138,27 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
       // tile's segments behind the previous tiles' and copy them out
       hipLaunchKernelGGL(vc_sort_segments_kernel, dim3(qt), dim3(1024), 0, s, wk->d_ring, cap, d_count, sorted_flag);
       R_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(vc_radius_offsets_kernel, dim3(1), dim3(1024), 0, s, d_count, qt, d_offsets + q0, d_tot);
+      const unsigned long long seq = (poll && q0 + TQ >= nq) ? ++wk->seq : 0ull;
+      hipLaunchKernelGGL(vc_radius_offsets_kernel, dim3(1), dim3(1024), 0, s, d_count, qt, d_offsets + q0, d_tot,
+                         (volatile unsigned long long*)wk->h_tot_dev, seq);
       R_CHECK(hipGetLastError());
       hipLaunchKernelGGL(vc_compact_segments_kernel, dim3(qt), dim3(256), 0, s, wk->d_ring, cap, d_offsets + q0, d_out, out_cap);
       R_CHECK(hipGetLastError());
     }
-    R_CHECK(hipMemcpyAsync(wk->h_tot, d_tot, 16, hipMemcpyDeviceToHost, s));
-    R_CHECK(hipStreamSynchronize(s));
+    // total + largest segment: the last offsets kernel wrote them to mapped host memory; the host polls the sequence word and
+    // returns while the last copy-out kernel may still run (results are in stream order; host readers copy behind it)
+    bool landed = false;
+    if (poll && nq) {
+      volatile unsigned long long* flag = wk->h_tot + 2;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (uint32_t spins = 0; !(landed = (*flag == wk->seq)); ++spins)
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!landed) {
+      R_CHECK(hipMemcpyAsync(wk->h_tot, d_tot, 16, hipMemcpyDeviceToHost, s));
+      R_CHECK(hipStreamSynchronize(s));
+    }
     const uint64_t mx = wk->h_tot[1];
     *total = wk->h_tot[0];
     if (mx <= cap) break;

@@ -76,7 +76,9 @@ int vc_mih_bitmap_read(VcMihIndex* ix, uint32_t table, uint64_t word_off, uint64
 struct VcRadiusWork {
   uint64_t *d_ring = nullptr, *d_compact = nullptr, *d_offs = nullptr;
   uint32_t* d_aux = nullptr;
-  unsigned long long* h_tot = nullptr;   // pinned: total entries and largest segment of a call
+  unsigned long long* h_tot = nullptr;   // pinned, mapped: total entries | largest segment | sequence number of the call that wrote them
+  unsigned long long* h_tot_dev = nullptr;
+  unsigned long long seq = 0;
   size_t aux_words = 0, offs_cap = 0;
   uint64_t compact_cap = 0;
   uint32_t cap = 0, tq = 0;
