@@ -572,7 +572,6 @@ __global__ void __launch_bounds__(256) mih_export_kernel(MihState st, const uint
   if (threadIdx.x == 0) cnt[q] = n;
 }
 
-__global__ void vc_add_u64_kernel(unsigned long long* p, unsigned long long v) { *p += v; }
 
 __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t n, uint32_t v) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1605,6 +1604,7 @@ __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamPara
     atomicAdd(&p.totals[1], s_tot[0]);
     atomicAdd(&p.totals[2], s_tot[1]);
     if (part == 0) atomicAdd(&p.totals[0], (unsigned long long)p.nprobes);
+    if (blockIdx.x == 0) atomicAdd(&p.totals[3], (unsigned long long)(gridDim.x / p.split));   // queries of the launch
   }
   // ---- every wave streams whole buckets
   uint64_t* const ring = p.ring + (uint64_t)slot * p.cap;
@@ -1819,26 +1819,14 @@ __global__ void __launch_bounds__(256) mih_minsub_count_kernel(const uint64_t* _
 }
 
 
-// sum the per-query work counters of one mih_query_kernel launch into the index-wide totals (vc_get_timing)
-__global__ void __launch_bounds__(1024) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
-                                                              unsigned long long* __restrict__ totals, uint32_t* __restrict__ ctr,
-                                                              volatile uint32_t* __restrict__ host_ctr, uint32_t seq) {
-  // the launch's counters (unfinished queries, where the others stopped) go straight to pinned host memory, followed by the
-  // launch's sequence number: the host polls that word instead of queueing a copy and waiting for the stream (every query
-  // kernel block has exited when this kernel runs, so the counters are final)
-  if (host_ctr && threadIdx.x == 0) {
-    for (uint32_t i = 2; i < 8; ++i) {
-      host_ctr[i] = ctr[i];
-      ctr[i] = 0;                        // ready for the next launch: no memset in front of it
-    }
-    __threadfence_system();
-    host_ctr[8] = seq;
-  }
+// sum the per-query work counters of one mih_query_kernel launch into the index-wide totals (vc_get_timing); one block
+// of 1024 threads: four 32-byte records per thread in flight -- one memory round trip for a tile of 4096 queries (the
+// serial form of this loop, 256 threads and one record per iteration, took 16 us behind every launch)
+__device__ __forceinline__ void mih_work_reduce_block(const unsigned long long* __restrict__ work, uint32_t nq,
+                                                      unsigned long long* __restrict__ totals) {
   __shared__ unsigned long long s_t[3];
   if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
   __syncthreads();
-  // one memory round trip for a tile of 4096 queries: four 32-byte records per thread in flight (the serial form of
-  // this loop -- 256 threads, one record per iteration -- took 16 us behind every launch)
   unsigned long long a = 0, b = 0, c = 0;
   const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(work);
   for (uint32_t base = 0; base < nq; base += 4 * blockDim.x) {
@@ -1871,35 +1859,65 @@ __global__ void __launch_bounds__(1024) mih_work_reduce_kernel(const unsigned lo
   if (threadIdx.x == 3) totals[3] += nq;
 }
 
-// per-query result segments of the radius search: ring[q][0 .. min(count, cap)) sorted ascending in place.
-// One 1024-thread block per query; segments the query kernel already sorted (flag) or empty ones are skipped.
-//   n <= 8192 : bitonic network in LDS;   larger: the same network on the segment itself (global memory), padded
-// to a power of two with VC_PACK_INF behind the entries (cap is a power of two).
-__global__ void __launch_bounds__(1024) vc_sort_segments_kernel(uint64_t* __restrict__ ring, uint32_t cap,
-                                                                const uint32_t* __restrict__ count,
-                                                                const uint32_t* __restrict__ sorted_flag) {
+__global__ void __launch_bounds__(1024) mih_work_reduce_kernel(const unsigned long long* __restrict__ work, uint32_t nq,
+                                                               unsigned long long* __restrict__ totals, uint32_t* __restrict__ ctr,
+                                                               volatile uint32_t* __restrict__ host_ctr, uint32_t seq) {
+  // the launch's counters (unfinished queries, where the others stopped) go straight to pinned host memory, followed by the
+  // launch's sequence number: the host polls that word instead of queueing a copy and waiting for the stream (every query
+  // kernel block has exited when this kernel runs, so the counters are final)
+  if (host_ctr && threadIdx.x == 0) {
+    for (uint32_t i = 2; i < 8; ++i) {
+      host_ctr[i] = ctr[i];
+      ctr[i] = 0;                        // ready for the next launch: no memset in front of it
+    }
+    __threadfence_system();
+    host_ctr[8] = seq;
+  }
+  mih_work_reduce_block(work, nq, totals);
+}
+
+// per-query result segments of the radius search -> one contiguous result array, ascending per query (positions beyond
+// out_cap are dropped; the caller learns the needed size from the offsets).  One 1024-thread block per query; a segment the
+// query kernel already sorted (flag) is copied, an unsorted one is ordered on the way:
+//   n <= 8192 : bitonic network in LDS, written straight to its place in `out`;
+//   larger    : the same network on the ring segment itself (global memory), padded to a power of two with VC_PACK_INF
+//               behind the entries (cap is a power of two), then copied.
+// (one launch where the sort and the copy-out used to be two)
+__global__ void __launch_bounds__(1024) vc_sort_compact_segments_kernel(uint64_t* __restrict__ ring, uint32_t cap,
+                                                                        const uint32_t* __restrict__ count,
+                                                                        const uint32_t* __restrict__ sorted_flag,
+                                                                        const uint64_t* __restrict__ offs,
+                                                                        uint64_t* __restrict__ out, uint64_t out_cap) {
   __shared__ uint64_t a[VC_SORT_CAP];
   const uint32_t q = blockIdx.x;
-  const uint32_t n = count[q];
-  if (n < 2 || n > cap || (sorted_flag && sorted_flag[q])) return;
+  const uint32_t n = min(count[q], cap);          // (a segment that outgrew the ring is repeated with a larger one)
+  const uint64_t lo = offs[q];
   uint64_t* seg = ring + (uint64_t)q * cap;
+  const bool sorted = n < 2 || count[q] > cap || (sorted_flag && sorted_flag[q]);
   uint32_t P = 2;
   while (P < n) P <<= 1;
-  if (P <= VC_SORT_CAP) {
+  if (!sorted && P <= VC_SORT_CAP) {
     for (uint32_t i = threadIdx.x; i < P; i += 1024) a[i] = i < n ? seg[i] : VC_PACK_INF;
     vc_bitonic_lds(a, P, 1024);
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) seg[i] = a[i];
-  } else {
+    for (uint32_t i = threadIdx.x; i < n; i += 1024)
+      if (lo + i < out_cap) out[lo + i] = a[i];
+    return;
+  }
+  if (!sorted) {
     for (uint32_t i = n + threadIdx.x; i < P; i += 1024) seg[i] = VC_PACK_INF;
     vc_bitonic_lds(seg, P, 1024);
   }
+  for (uint32_t i = threadIdx.x; i < n; i += 1024)
+    if (lo + i < out_cap) out[lo + i] = seg[i];
 }
 
 // exclusive prefix of one tile's segment lengths behind the running total of the call:
 // offsets[i] = tot[0] + sum_{j<i} count[j];  tot[0] += sum;  tot[1] = max(tot[1], max count)  (overflow detection)
 __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t* __restrict__ count, uint32_t nq,
-                                                                 uint64_t* __restrict__ offsets, unsigned long long* tot,
-                                                                 volatile unsigned long long* host_tot, unsigned long long seq) {
+                                                                 uint64_t* __restrict__ offsets, unsigned long long* tot, uint32_t first,
+                                                                 volatile unsigned long long* host_tot, unsigned long long seq,
+                                                                 const unsigned long long* __restrict__ work,
+                                                                 unsigned long long* __restrict__ totals) {
   __shared__ uint64_t s_w[1024 / VC_WAVE];
   __shared__ uint32_t s_max;
   const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
@@ -1919,7 +1937,8 @@ __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t*
   if (lane == 0) s_w[wave] = wtot;
   atomicMax(&s_max, mx);
   __syncthreads();
-  uint64_t base = tot[0], total = 0;
+  const uint64_t tot0 = first ? 0ull : tot[0], max0 = first ? 0ull : tot[1];   // (first tile of a call: the totals start over)
+  uint64_t base = tot0, total = 0;
   for (uint32_t w = 0; w < 1024 / VC_WAVE; ++w) {
     if (w < wave) base += s_w[w];
     total += s_w[w];
@@ -1933,9 +1952,9 @@ __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t*
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    offsets[nq] = tot[0] + total;
-    tot[0] += total;
-    if (s_max > tot[1]) tot[1] = s_max;
+    offsets[nq] = tot0 + total;
+    tot[0] = tot0 + total;
+    tot[1] = s_max > max0 ? (unsigned long long)s_max : max0;
     if (host_tot && seq) {   // last tile of a call: total and largest segment go to mapped host memory, the call's sequence number last
       host_tot[0] = tot[0];
       host_tot[1] = tot[1];
@@ -1943,17 +1962,7 @@ __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t*
       host_tot[2] = seq;
     }
   }
-}
-
-// sorted ring segments -> one contiguous result array (positions beyond out_cap are dropped; the caller learns the
-// needed size from the offsets)
-__global__ void __launch_bounds__(256) vc_compact_segments_kernel(const uint64_t* __restrict__ ring, uint32_t cap,
-                                                                  const uint64_t* __restrict__ offs,
-                                                                  uint64_t* __restrict__ out, uint64_t out_cap) {
-  const uint32_t q = blockIdx.x;
-  const uint64_t lo = offs[q], n = offs[q + 1] - offs[q];
-  for (uint64_t i = threadIdx.x; i < n && i < cap; i += blockDim.x)
-    if (lo + i < out_cap) out[lo + i] = ring[(uint64_t)q * cap + i];
+  if (work) mih_work_reduce_block(work, nq, totals);   // the query kernel's work counters (vc_get_timing), behind the publication
 }
 
 }  // namespace
@@ -2677,8 +2686,10 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
   hipError_t r = launch_query_kernel(p, W, nq, s);
   if (ev) (void)hipEventRecord(ev->second, s);
   if (r != hipSuccess) return r;
-  // (k-NN launches only: heavy_ctr = the tile's counter block + 2; radius search has no counters to publish)
-  hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(1024), 0, s, p.st.work, nq, ix->d_totals,
+  // (k-NN launches: heavy_ctr = the tile's counter block + 2.  Radius search has no counters to publish, and its work
+  // counters are summed by vc_radius_offsets_kernel, which follows anyway)
+  if (p.mode != MQ_MODE_RADIUS)
+    hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(1024), 0, s, p.st.work, nq, ix->d_totals,
                      p.heavy_ctr ? p.heavy_ctr - 2 : (uint32_t*)nullptr,
                      p.heavy_ctr ? (volatile uint32_t*)ix->h_ctr_dev : (volatile uint32_t*)nullptr, ++ix->ctr_seq);
   if (p.phase_dbg) {
@@ -2724,9 +2735,7 @@ static hipError_t timed_stream_launch(VcMihIndex* ix, StreamParams sp, uint32_t 
   }
   hipError_t r = hipGetLastError();
   if (ev) (void)hipEventRecord(ev->second, s);
-  if (r != hipSuccess) return r;
-  hipLaunchKernelGGL(vc_add_u64_kernel, dim3(1), dim3(1), 0, s, ix->d_totals + 3, (unsigned long long)nq);
-  return hipGetLastError();
+  return r;
 }
 
 void vc_mih_timing(VcMihIndex* ix, float* ms, uint32_t* launches, uint64_t totals[4], hipStream_t s) {
@@ -3081,10 +3090,11 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
       R_CHECK(hipMalloc((void**)&wk->d_ring, (size_t)TQ * cap * 8));
       wk->cap = cap;
     }
-    R_CHECK(hipMemsetAsync(d_tot, 0, 16, s));
+    if (nq == 0) R_CHECK(hipMemsetAsync(d_tot, 0, 16, s));   // (else the first tile's offsets kernel starts the totals over)
     for (uint32_t q0 = 0; q0 < nq; q0 += TQ) {
       const uint32_t qt = std::min(TQ, nq - q0);
       const uint32_t* sorted_flag = nullptr;
+      const unsigned long long* work = nullptr;   // mih_query_kernel's per-query work counters of this tile
       if (use_mih) {
         if ((rc = ensure_tile(ix, 1, 1, false, &st, err))) return rc;
         st.ring = wk->d_ring;   // radius search keeps every neighbour: the big ring instead of the tile's
@@ -3098,6 +3108,7 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
           qp.buf_entries = 2048;
           R_CHECK(timed_query_launch(ix, qp, W, qt, s));
           sorted_flag = d_sorted;
+          work = st.work;
         } else if (stream) {
           uint32_t* list = ix->d_lists;
           hipLaunchKernelGGL(mih_init_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, qt, list, vc_pack(radius + 1, 0));
@@ -3134,15 +3145,14 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
         p.hist = d_hist; p.buf = wk->d_ring;
         R_CHECK(vc_launch_scan(p, W, n_cu, 0, knobs, s));
       }
-      // order every segment (hand-written bitonic network; the query kernel's small segments arrive sorted), place the
-      // tile's segments behind the previous tiles' and copy them out
-      hipLaunchKernelGGL(vc_sort_segments_kernel, dim3(qt), dim3(1024), 0, s, wk->d_ring, cap, d_count, sorted_flag);
-      R_CHECK(hipGetLastError());
+      // place the tile's segments behind the previous tiles' (+ the call's totals, + the query kernel's work counters), then
+      // order what did not arrive sorted (hand-written bitonic network; the query kernel's small segments do) and copy out
       const unsigned long long seq = (poll && q0 + TQ >= nq) ? ++wk->seq : 0ull;
-      hipLaunchKernelGGL(vc_radius_offsets_kernel, dim3(1), dim3(1024), 0, s, d_count, qt, d_offsets + q0, d_tot,
-                         (volatile unsigned long long*)wk->h_tot_dev, seq);
+      hipLaunchKernelGGL(vc_radius_offsets_kernel, dim3(1), dim3(1024), 0, s, d_count, qt, d_offsets + q0, d_tot, q0 == 0 ? 1u : 0u,
+                         (volatile unsigned long long*)wk->h_tot_dev, seq, work, work ? ix->d_totals : (unsigned long long*)nullptr);
       R_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(vc_compact_segments_kernel, dim3(qt), dim3(256), 0, s, wk->d_ring, cap, d_offsets + q0, d_out, out_cap);
+      hipLaunchKernelGGL(vc_sort_compact_segments_kernel, dim3(qt), dim3(1024), 0, s, wk->d_ring, cap, d_count, sorted_flag,
+                         d_offsets + q0, d_out, out_cap);
       R_CHECK(hipGetLastError());
     }
     // total + largest segment: the last offsets kernel wrote them to mapped host memory; the host polls the sequence word and
