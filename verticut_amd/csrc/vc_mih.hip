@@ -1865,13 +1865,17 @@ __global__ void __launch_bounds__(1024) mih_work_reduce_kernel(const unsigned lo
   // the launch's counters (unfinished queries, where the others stopped) go straight to pinned host memory, followed by the
   // launch's sequence number: the host polls that word instead of queueing a copy and waiting for the stream (every query
   // kernel block has exited when this kernel runs, so the counters are final)
-  if (host_ctr && threadIdx.x == 0) {
-    for (uint32_t i = 2; i < 8; ++i) {
-      host_ctr[i] = ctr[i];
-      ctr[i] = 0;                        // ready for the next launch: no memset in front of it
+  // (block 1 of the two: the system-scope fence takes ~4 us, as long as the summation block 0 does meanwhile)
+  if (blockIdx.x == 1) {
+    if (host_ctr && threadIdx.x == 0) {
+      for (uint32_t i = 2; i < 8; ++i) {
+        host_ctr[i] = ctr[i];
+        ctr[i] = 0;                        // ready for the next launch: no memset in front of it
+      }
+      __threadfence_system();
+      host_ctr[8] = seq;
     }
-    __threadfence_system();
-    host_ctr[8] = seq;
+    return;
   }
   mih_work_reduce_block(work, nq, totals);
 }
@@ -1918,6 +1922,10 @@ __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t*
                                                                  volatile unsigned long long* host_tot, unsigned long long seq,
                                                                  const unsigned long long* __restrict__ work,
                                                                  unsigned long long* __restrict__ totals) {
+  if (blockIdx.x == 1) {   // second block (launched when `work` is given): the query kernel's work counters (vc_get_timing)
+    mih_work_reduce_block(work, nq, totals);
+    return;
+  }
   __shared__ uint64_t s_w[1024 / VC_WAVE];
   __shared__ uint32_t s_max;
   const uint32_t lane = vc_lane(), wave = threadIdx.x / VC_WAVE;
@@ -1962,7 +1970,6 @@ __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t*
       host_tot[2] = seq;
     }
   }
-  if (work) mih_work_reduce_block(work, nq, totals);   // the query kernel's work counters (vc_get_timing), behind the publication
 }
 
 }  // namespace
@@ -2689,7 +2696,7 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
   // (k-NN launches: heavy_ctr = the tile's counter block + 2.  Radius search has no counters to publish, and its work
   // counters are summed by vc_radius_offsets_kernel, which follows anyway)
   if (p.mode != MQ_MODE_RADIUS)
-    hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(1), dim3(1024), 0, s, p.st.work, nq, ix->d_totals,
+    hipLaunchKernelGGL(mih_work_reduce_kernel, dim3(2), dim3(1024), 0, s, p.st.work, nq, ix->d_totals,
                      p.heavy_ctr ? p.heavy_ctr - 2 : (uint32_t*)nullptr,
                      p.heavy_ctr ? (volatile uint32_t*)ix->h_ctr_dev : (volatile uint32_t*)nullptr, ++ix->ctr_seq);
   if (p.phase_dbg) {
@@ -3148,7 +3155,7 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
       // place the tile's segments behind the previous tiles' (+ the call's totals, + the query kernel's work counters), then
       // order what did not arrive sorted (hand-written bitonic network; the query kernel's small segments do) and copy out
       const unsigned long long seq = (poll && q0 + TQ >= nq) ? ++wk->seq : 0ull;
-      hipLaunchKernelGGL(vc_radius_offsets_kernel, dim3(1), dim3(1024), 0, s, d_count, qt, d_offsets + q0, d_tot, q0 == 0 ? 1u : 0u,
+      hipLaunchKernelGGL(vc_radius_offsets_kernel, dim3(work ? 2 : 1), dim3(1024), 0, s, d_count, qt, d_offsets + q0, d_tot, q0 == 0 ? 1u : 0u,
                          (volatile unsigned long long*)wk->h_tot_dev, seq, work, work ? ix->d_totals : (unsigned long long*)nullptr);
       R_CHECK(hipGetLastError());
       hipLaunchKernelGGL(vc_sort_compact_segments_kernel, dim3(qt), dim3(1024), 0, s, wk->d_ring, cap, d_count, sorted_flag,
