@@ -526,3 +526,37 @@ def test_radius_search_through_the_bucket_streaming_kernel(vc, oracle, monkeypat
             for i in range(0, nq, max(1, nq // 25)):
                 ores, _ = mo.radius(qq[i], m + 2)
                 assert np.array_equal(mih[i], ores), (nq, i)
+
+
+def test_polled_and_synchronised_waits_return_the_same(vc, oracle, monkeypatch):
+    """The host learns a k-NN launch's unfinished-query counter and a radius call's total from mapped host memory, polling
+    the sequence number the device writes last (VC_MIH_POLL=1, default), or with a read-back copy + hipStreamSynchronize
+    (=0): same rows, counts, statistics and radius results, also for queries that continue in the multi-block shells and
+    for calls of more than one 4096-query tile."""
+    n, bits, m, k = 80000, 128, 4, 20
+    rng = np.random.default_rng(9)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=300, max_flips=9)
+    q = np.concatenate([_near_queries(codes, 4300, rng, 5), rng.integers(0, 256, size=(3, 16), dtype=np.uint8)])
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VC_MIH_POLL", flag)
+        with vc.Engine(bits, capacity=n, n_tables=m) as e:
+            e.add_codes(codes)
+            e.build_index()
+            res, cnt, st = e.search_knn(q, k, mode=vc.MODE_MIH_EXACT, with_stats=True)
+            res2, cnt2 = e.search_knn(q[:50], k, mode=vc.MODE_MIH_EXACT)
+            rad = e.search_radius(q[:4200], 6, mode=vc.MODE_MIH_EXACT)
+            rad2 = e.search_radius(q[:7], 6, mode=vc.MODE_MIH_EXACT)
+            out[flag] = (res, cnt, [(s.radius, s.n_sub_reads, s.n_candidates) for s in st], res2, cnt2, rad, rad2)
+    a, b = out["1"], out["0"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert np.array_equal(a[0][:50], a[3])
+    assert len(a[5]) == len(b[5]) and all(np.array_equal(x, y) for x, y in zip(a[5], b[5]))
+    assert all(np.array_equal(x, y) for x, y in zip(a[6], b[6])) and all(np.array_equal(x, y) for x, y in zip(a[6], a[5][:7]))
+    with vc.Engine(bits, capacity=n, n_tables=m) as e:
+        e.add_codes(codes)
+        lin, lcnt = e.search_knn(q[-3:], k)
+        assert np.array_equal(a[0][-3:] >> SH, lin >> SH)      # the uniform queries went through the multi-block shells or the switch
+        exp = e.search_radius(q[:7], 6, mode=vc.MODE_LINEAR)
+        assert all(np.array_equal(x, y) for x, y in zip(a[6], exp))
