@@ -560,3 +560,57 @@ def test_polled_and_synchronised_waits_return_the_same(vc, oracle, monkeypatch):
         assert np.array_equal(a[0][-3:] >> SH, lin >> SH)      # the uniform queries went through the multi-block shells or the switch
         exp = e.search_radius(q[:7], 6, mode=vc.MODE_LINEAR)
         assert all(np.array_equal(x, y) for x, y in zip(a[6], exp))
+
+
+def test_work_counters_of_vc_get_timing_are_the_closed_forms(vc, oracle, monkeypatch):
+    """vc_get_timing's MIH totals (the algorithmic bytes of bench.py's roofline come from them): probes per query are the closed
+    forms of search_worker.cc:222-264 / :170-207 -- radius search: the pigeonhole shells of every table; exact k-NN: m x the
+    leaves of shells 0 .. radius of each query -- and the query count is the number of queries, whichever kernel summed them
+    (mih_work_reduce_kernel, the radius offsets kernel, the bucket streaming kernel)."""
+    from math import comb
+    monkeypatch.setenv("VC_MIH_BUDGET", "600000")                 # shells 0..4 inside the query kernel whatever the batch size
+    n = 60000
+    rng = np.random.default_rng(17)
+    # 64-bit, m = 2 (32-bit substrings): R = 8 -> radii 4 and 3
+    codes = oracle.gen_codes(n, 64, 34, kind=1, n_centres=300, max_flips=6)
+    q = _near_queries(codes, 37, rng, 3)
+    with vc.Engine(64, capacity=n, n_tables=2) as e:
+        e.add_codes(codes)
+        e.build_index()
+        e.timing()
+        e.search_radius(q, 8, mode=vc.MODE_MIH_EXACT)
+        t = e.timing()
+        per_query = sum(comb(32, r) for r in range(5)) + sum(comb(32, r) for r in range(4))
+        assert per_query == 46938
+        assert (t.mih_queries, t.mih_probes) == (len(q), len(q) * per_query) and t.mih_launches == 1
+        assert 0 < t.mih_hits <= t.mih_entries
+        res, cnt, st = e.search_knn(q, 10, mode=vc.MODE_MIH_EXACT, with_stats=True)
+        t = e.timing()
+        assert max(s.radius for s in st) <= 4                    # everything finished inside the query kernel
+        assert t.mih_queries == len(q) and t.mih_probes == sum(2 * sum(comb(32, r) for r in range(s.radius + 1)) for s in st)
+    # 64-bit, m = 4 (16-bit substrings): R = 8 -> radius 2 for table 0, 1 for the others; small buckets: the query kernel
+    with vc.Engine(64, capacity=n, n_tables=4) as e:
+        e.add_codes(codes)
+        e.build_index()
+        e.timing()
+        e.search_radius(q, 8, mode=vc.MODE_MIH_EXACT)
+        t = e.timing()
+        per_query = sum(comb(16, r) for r in range(3)) + 3 * sum(comb(16, r) for r in range(2))
+        assert per_query == 188
+        assert (t.mih_queries, t.mih_probes) == (len(q), len(q) * per_query)
+
+
+def test_work_counters_of_the_bucket_streaming_kernel(vc, oracle, monkeypatch):
+    from math import comb
+    monkeypatch.setenv("VC_MIH_STREAM", "2")                      # small databases through mih_bucket_stream_kernel too
+    n = 50000
+    rng = np.random.default_rng(18)
+    codes = oracle.gen_codes(n, 64, 34, kind=1, n_centres=300, max_flips=6)
+    q = _near_queries(codes, 21, rng, 3)
+    with vc.Engine(64, capacity=n, n_tables=4) as e:
+        e.add_codes(codes)
+        e.build_index()
+        e.timing()
+        e.search_radius(q, 8, mode=vc.MODE_MIH_EXACT)
+        t = e.timing()
+        assert (t.mih_queries, t.mih_probes) == (len(q), len(q) * 188) and t.mih_entries >= t.mih_hits > 0
