@@ -597,11 +597,19 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 // Per block: hits (non-empty buckets) are compacted into an LDS list; when it holds >= MQ_HFLUSH entries (and at the
 // end of a shell) it is DRAINED: rank -> offsets for the 32-bit tables, block prefix sum of the bucket lengths,
 // balanced expansion of the entries over the threads (binary search in the LDS prefix array), gather of id + code,
-// full distance + every substring distance, OWNER RULE (vc_mih.hip mih_probe_kernel), survivors below the current
-// k-th best appended behind the top-k in LDS.  The top-k array and the fresh candidates share one LDS buffer that is
-// bitonic-sorted when a shell ends (or when it fills), which also yields the new threshold and the stop rule's k-th
-// distance.  A query that is not finished after shell r_last (the shells beyond cost > 10^5 probes) writes its state
-// to the slot arrays and joins the `heavy` list, which the multi-block kernels above continue from shell r_last + 1.
+// full distance + every substring distance, OWNER RULE (vc_mih.hip mih_probe_kernel), survivors below the running
+// threshold appended to an UNSORTED candidate buffer in LDS and counted in a distance histogram.  After a shell one
+// wave cuts the histogram (smallest d whose cumulative count reaches k): that is the stop rule's k-th distance and the
+// next threshold; the buffer is compacted when it fills and ordered once, when the query ends (k-NN modes; radius
+// search sorts its results once at the end).  The first pass of 32-bit substrings covers shells 0 .. group-1 together:
+// candidates carry their shell class in the two top bits of the packed value, histogram / seen / bitmap-hit counters
+// exist per class, and the stop rule is then evaluated shell by shell -- same results and statistics, one scan / drain
+// round instead of one per shell.  A pass gives every thread MQ_GPT_KNN granules (6: shell 2's 1 304 granules of four
+// tables are one pass).  A query that is not finished after shell r_last (the shells beyond cost > 10^5 probes) writes
+// its state to the slot arrays and joins the `heavy` list, which the multi-block kernels above continue from shell
+// r_last + 1.  The kernel sits at the 128-VGPR limit of its 4 waves per SIMD (tests/test_build_cpu.py guards it):
+// result / state pointers are read from the kernel-argument segment where they are used (cold()), per-query counters
+// live in LDS, and the rare buffer paths (mq_compact, mq_select_exact) are functions of their own.
 // =============================================================================================================
 #ifndef MQ_BLK
 #define MQ_BLK 256u
