@@ -478,6 +478,22 @@ def _mih_roofline(tm, bits, kernel="mih_query_kernel"):
     }
 
 
+# The yardstick that fits the MIH kernels: 64-byte requests per second against the random-sector ceiling of the memory
+# system, measured with tools/ubench_sectors.hip (independent 4..64-byte loads from uniformly random 64-byte sectors,
+# profiles/r03_ubench_sectors.txt): 54 G sectors/s over a 2 GB footprint (the four occupancy bitmaps), 49-50 G over
+# 16-128 GB (the bucket-order records at 1e9).
+SECTOR_PEAK_G = 54.0
+
+
+def _add_sector_roofline(roof):
+    """roofline.sectors: the kernel's measured 64-byte requests per launch / its launch time, against the random-sector ceiling"""
+    if roof.get("traffic") and roof.get("avg_launch_ms"):
+        ach = roof["traffic"] / 64.0 / (roof["avg_launch_ms"] * 1e-3) / 1e9
+        roof["sectors"] = {"achieved": ach, "peak": SECTOR_PEAK_G, "unit": "G 64-byte requests/s", "frac": ach / SECTOR_PEAK_G,
+                           "peak_how": "tools/ubench_sectors.hip on one MI355X: independent random-sector loads, 2 GB footprint "
+                                       "(profiles/r03_ubench_sectors.txt; 49-50 G over 16-128 GB)"}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # extras of the default line: short measurements of the other shapes in the SAME invocation, so that the driver's
 # record carries them too (each: whole-call queries/s, the dominant kernel's average launch time and its algorithmic
@@ -674,6 +690,8 @@ def run_c2(args, env, emit):
         # memory-side requests of the query kernel (64 bytes each); the x2 of a wide stream does not apply to 16-byte gathers
         t, how = measure_traffic(args, "mih_query_kernel", fetch_mult=1.0, extra=("--tables", str(m0)))
         line["roofline"]["traffic"], line["roofline"]["traffic_how"] = t, how + " (64-byte requests of 16-byte granule loads and gathers; uncorrected)"
+        if lines[m0]["roofline"].get("kernel") == "mih_query_kernel":
+            _add_sector_roofline(line["roofline"])
     if args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline_mih(args, m0, "radius", radius=radius)
     emit(line)
@@ -731,6 +749,8 @@ def run_knn_mih(args, env, emit):
     if not args.no_traffic:
         t, how = measure_traffic(args, "mih_query_kernel", fetch_mult=1.0)
         line["roofline"]["traffic"], line["roofline"]["traffic_how"] = t, how + " (64-byte requests of 16-byte granule loads and gathers; uncorrected)"
+        if line["roofline"].get("kernel") == "mih_query_kernel":
+            _add_sector_roofline(line["roofline"])
     if args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline_mih(args, m, "knn", clustered=True)
     emit(line)

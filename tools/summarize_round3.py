@@ -111,6 +111,13 @@ for w, bname, kernel in (("knn_mih_1e9", "knn_mih_1e9", "mih_query_kernel"), ("k
     }
     if rl.get("algorithmic_bytes_per_launch"):
         out["traffic_over_algorithmic_raw"] = raw / rl["algorithmic_bytes_per_launch"]
+    if kernel == "mih_query_kernel":
+        # the yardstick of a gather kernel: 64-byte requests per second against the random-sector ceiling measured with
+        # tools/ubench_sectors.hip (profiles/r03_ubench_sectors.txt): 54 G/s over a 2 GB footprint, 49-50 G/s over 16-128 GB
+        peak = 50.0 if w == "knn_mih_1e9" else 54.0
+        ach = raw / 64.0 / (fetch["pass_avg_ms"] * 1e-3) / 1e9
+        out["sectors"] = {"achieved_G_per_s": ach, "peak_G_per_s": peak, "frac": ach / peak,
+                          "peak_how": "tools/ubench_sectors.hip: independent random-sector loads, %s footprint" % ("64-128 GB" if w == "knn_mih_1e9" else "2 GB")}
     json.dump(out, open("%s_mih_%s_pmc.json" % (prefix, w), "w"), indent=1)
     print("%s pmc: FETCH %.0f KB/launch (raw %.1f MB = %.2f TB/s), L2 hit rate %s, algorithmic %.1f MB/launch" % (
         w, fetch["FETCH_SIZE"], raw / 1e6, out["memory_side_GBps_raw"] / 1e3, out["l2_hit_rate"],
