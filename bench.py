@@ -464,7 +464,12 @@ def _mih_roofline(tm, bits, kernel="mih_query_kernel"):
                 "kernel": "mih_probe_kernel", "note": "this shape (buckets of ~1500 entries) runs the multi-block shell kernels, "
                 "one launch sequence per shell; only mih_query_kernel is instrumented"}
     launches = max(tm.mih_launches, 1)
-    alg = (tm.mih_probes * 4 + tm.mih_hits * 16 + tm.mih_entries * (4 + bits // 8)) / launches
+    if kernel == "mih_bucket_stream_kernel":
+        # the streaming kernel reads two offsets per probe and the CODES of the bucket entries (bucket-order copy); ids are
+        # gathered for results only -- SURVEY 8(d)'s per-entry figure (id + code) would price bytes nobody reads
+        alg = (tm.mih_probes * 8 + tm.mih_entries * (bits // 8)) / launches
+    else:
+        alg = (tm.mih_probes * 4 + tm.mih_hits * 16 + tm.mih_entries * (4 + bits // 8)) / launches
     avg_ms = tm.mih_ms / launches
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     return {

@@ -1528,14 +1528,21 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 //   * a block takes one query (or one of `split` interleaved parts of its probe list), its threads look the probes up
 //     once (key by combination unranking, direct offsets: search_worker.cc:230-246) into an LDS list of (offset, length);
 //   * every WAVE then streams whole buckets from the table's bucket-order code copy (VcTableView::bcodes: contiguous,
-//     512 bytes per wave-instruction, MS_U instructions in flight per lane) and tests the FULL distance only:
-//     xor + popcount + compare per entry, no id load, no LDS search, no workgroup barrier in the loop;
-//   * the rare entry within the radius pays for the owner rule (per-substring distances) and its id, and is appended to
-//     the query's result ring with one atomic per wave.
+//     two entries per lane and 16-byte load = 1 KB per wave-instruction, MS_UP of them in flight per lane) and tests the
+//     FULL distance only: xor + popcount + compare per entry, no id load, no LDS search, no workgroup barrier in the loop;
+//   * an entry within the radius pays for the owner rule (per-substring distances) and is staged in the wave's LDS buffer
+//     as (table, distance, position); every ~64-128 results the wave reserves ring space with ONE atomic and gathers
+//     their ids together (a returning atomic and a gather per group of hits stalled the stream ~500 times per query).
 // Algorithmic bytes: probes x 8 (two offsets) + entries x B/8; measured by the kernel's own counters (vc_timing.mih_*).
 // =============================================================================================================
 #ifndef MS_U
 #define MS_U 8u                          // bucket entries per lane in flight
+#endif
+#ifndef MS_UP
+#define MS_UP 8u                         // ... 16-byte pairs per lane in flight (pair path: 128 bytes per lane)
+#endif
+#ifndef MS_STAGE
+#define MS_STAGE 128u                     // results a wave stages in LDS between two flushes (>= 128)
 #endif
 #ifndef MS_MAXP
 #define MS_MAXP 2048u                    // probes of one query (all tables, all shells) held in LDS
@@ -1556,6 +1563,7 @@ struct StreamParams {
 template <int W>
 __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamParams p) {
   __shared__ uint32_t s_off[MS_MAXP], s_len[MS_MAXP], s_meta[MS_MAXP];
+  __shared__ uint64_t s_stage[256 / VC_WAVE][MS_STAGE];   // per wave: results awaiting their ids and ring space
   __shared__ unsigned long long s_tot[2];
   const uint32_t slot = blockIdx.x / p.split, part = blockIdx.x % p.split;
   const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
@@ -1616,10 +1624,89 @@ __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamPara
   }
   // ---- every wave streams whole buckets
   uint64_t* const ring = p.ring + (uint64_t)slot * p.cap;
+  // Results are staged per wave: a group of hits used to cost the wave a returning global atomic (ring space) and a gather
+  // (ids[pos]) on the spot -- two round trips in the middle of the stream, ~500 times per query; now one of each per
+  // MS_STAGE - 64 .. MS_STAGE results.
+  uint64_t* const stage = s_stage[wave];
+  uint32_t fill = 0;                                   // (wave-uniform)
+  auto flush = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, in program order (see mih_tile... history)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&p.count[slot], fill);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (uint32_t i = lane; i < fill; i += VC_WAVE) {
+      const uint64_t h = stage[i];
+      const uint32_t at = base + i;
+      if (at < p.cap) ring[at] = vc_pack((uint32_t)(h >> 32) & 0xFFFFu, p.id_base + p.tables[(uint32_t)(h >> 48)].ids[(uint32_t)h]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    fill = 0;
+  };
+  // one entry of bucket b (table t, substring distance dt of its key), code words x, position pos in the table's entry arrays
+  auto entry = [&](const uint64_t (&x)[W], bool valid, uint32_t pos, uint32_t t, uint32_t dt) {
+    uint32_t dist = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) dist += (uint32_t)__popcll(x[j] ^ qw[j]);
+    bool hit = valid && dist <= p.radius;
+    if (__ballot(hit) == 0) return;
+    if (hit) {   // owner rule (mih_probe_kernel): reported by the first table holding the minimum substring distance
+      for (uint32_t tt = 0; tt < m; ++tt) {
+        const uint32_t bp = tt * s;
+        uint32_t field = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          if ((uint32_t)j == (bp >> 6)) field = (uint32_t)((x[j] ^ qw[j]) >> (bp & 63)) & smask;
+        const uint32_t d = __popc(field);
+        bool reach = true;
+        if (p.flags & VC_FLAG_REF_SIGNEXT_KEYS) reach = ((field >> (s - 1)) & 1u) == 0;
+        if (tt != t && reach && (d < dt || (d == dt && tt < t))) hit = false;
+      }
+    }
+    const uint64_t km = __ballot(hit);
+    if (km == 0) return;
+    // staged in the wave's LDS buffer as (table, distance, entry position); ids and ring space are fetched per flush
+    if (hit) stage[fill + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = ((uint64_t)t << 48) | ((uint64_t)dist << 32) | pos;
+    fill += (uint32_t)__popcll(km);
+    if (fill >= MS_STAGE - VC_WAVE) flush();
+  };
+  // 16-byte loads -- two consecutive entries per lane, 1 KB per wave-instruction -- wherever every column of the copy keeps
+  // even positions 16-byte aligned (one-word codes, or an even entry count); the copies are padded by one entry so that the
+  // pair that holds the table's last entry stays inside the allocation
+  const bool pairs = W == 1 || (p.n & 1ull) == 0;
   for (uint32_t b = wave; b < nloc; b += blockDim.x / VC_WAVE) {
     const uint32_t off = s_off[b], len = s_len[b], t = s_meta[b] & 0xFFu, dt = s_meta[b] >> 8;
     if (len == 0) continue;
     const uint64_t* bc = p.tables[t].bcodes;
+    if (pairs) {
+      const uint32_t a0 = off & ~1u, end = off + len;
+      for (uint32_t e0 = a0; e0 < end; e0 += VC_WAVE * MS_UP * 2) {
+        vc_u64x2 v[MS_UP][W];
+#pragma unroll
+        for (uint32_t u = 0; u < MS_UP; ++u) {
+          const uint32_t pa = e0 + (u * VC_WAVE + lane) * 2;
+          const uint32_t pc = pa < end ? pa : a0;           // clamp: the bucket's first pair exists
+#pragma unroll
+          for (int j = 0; j < W; ++j) v[u][j] = __builtin_nontemporal_load(reinterpret_cast<const vc_u64x2*>(bc + (uint64_t)j * p.n + pc));
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < MS_UP; ++u) {
+          const uint32_t pa = e0 + (u * VC_WAVE + lane) * 2;
+          uint64_t xa[W], xb[W];
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            xa[j] = v[u][j].x;
+            xb[j] = v[u][j].y;
+          }
+          entry(xa, pa >= off && pa < end, pa, t, dt);
+          entry(xb, pa + 1 < end, pa + 1, t, dt);              // (pa + 1 > off always)
+        }
+      }
+      continue;
+    }
     for (uint32_t e0 = 0; e0 < len; e0 += VC_WAVE * MS_U) {
       uint64_t x[MS_U][W];
 #pragma unroll
@@ -1632,36 +1719,11 @@ __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamPara
 #pragma unroll
       for (uint32_t u = 0; u < MS_U; ++u) {
         const uint32_t e = e0 + u * VC_WAVE + lane;
-        uint32_t dist = 0;
-#pragma unroll
-        for (int j = 0; j < W; ++j) dist += (uint32_t)__popcll(x[u][j] ^ qw[j]);
-        bool hit = e < len && dist <= p.radius;
-        if (__ballot(hit) == 0) continue;
-        if (hit) {   // owner rule (mih_probe_kernel): reported by the first table holding the minimum substring distance
-          for (uint32_t tt = 0; tt < m; ++tt) {
-            const uint32_t bp = tt * s;
-            uint32_t field = 0;
-#pragma unroll
-            for (int j = 0; j < W; ++j)
-              if ((uint32_t)j == (bp >> 6)) field = (uint32_t)((x[u][j] ^ qw[j]) >> (bp & 63)) & smask;
-            const uint32_t d = __popc(field);
-            bool reach = true;
-            if (p.flags & VC_FLAG_REF_SIGNEXT_KEYS) reach = ((field >> (s - 1)) & 1u) == 0;
-            if (tt != t && reach && (d < dt || (d == dt && tt < t))) hit = false;
-          }
-        }
-        const uint64_t km = __ballot(hit);
-        if (km == 0) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&p.count[slot], (uint32_t)__popcll(km));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (hit) {
-          const uint32_t at = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
-          if (at < p.cap) ring[at] = vc_pack(dist, p.id_base + p.tables[t].ids[off + e]);
-        }
+        entry(x[u], e < len, off + e, t, dt);
       }
     }
   }
+  if (fill) flush();
 }
 
 
@@ -2208,7 +2270,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
     tv.bcodes = nullptr;
     if (want_bcodes && n) {
       uint64_t* bc = nullptr;
-      B_CHECK(dalloc((void**)&bc, (size_t)n * W * 8, true));
+      B_CHECK(dalloc((void**)&bc, (size_t)n * W * 8 + 16, true));   // (+ one entry: mih_bucket_stream_kernel reads 16-byte pairs)
       hipLaunchKernelGGL(mih_bcodes_kernel, dim3(grid_for(n * W, n_cu)), dim3(256), 0, s, d_cols, stride, W, ids, n, bc);
       B_CHECK(hipGetLastError());
       tv.bcodes = bc;
@@ -2560,7 +2622,7 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
     }
     if (want_bcodes && n) {
       uint64_t* bc = nullptr;
-      if ((rc = dalloc((void**)&bc, (size_t)n * W * 8))) break;
+      if ((rc = dalloc((void**)&bc, (size_t)n * W * 8 + 16))) break;
       hipLaunchKernelGGL(mih_bcodes_kernel, dim3(grid_for(n * W, n_cu)), dim3(256), 0, s, d_cols, stride, W, ids, n, bc);
       tv.bcodes = bc;
     }
