@@ -183,8 +183,10 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
                   uint64_t* out, uint32_t* counts, vc_query_stats* stats);
 /* Device-pointer variant for callers that keep queries/results in HBM (torch / multi-GPU merge).
  * d_queries: nq*bits/8 bytes; d_out: nq*k uint64, ascending, padded with UINT64_MAX; d_counts: nq uint32.
- * Asynchronous on `stream` and ordered like any other work enqueued there when mode == VC_MODE_LINEAR; other
- * modes synchronise that stream.
+ * Asynchronous on `stream` and ordered like any other work enqueued there when mode == VC_MODE_LINEAR; the MIH
+ * modes make the host wait until the batch's query kernel has finished (how many queries continue in the multi-block
+ * shells decides what is enqueued next), so their rows are complete when the call returns; results are valid in
+ * stream order in every mode.
  * A candidate-ring overflow (more than cand_cap items at or below the k-th distance: duplicate-heavy data,
  * linear_search.cc:113-117 mentions 250 000-entry buckets) is recovered exactly ON THE DEVICE in the same stream
  * (radix select over the position of the tied items), so a LINEAR row is always exact.  Only if that
