@@ -43,6 +43,25 @@ __global__ void __launch_bounds__(256) k_sectors(const uint32_t* __restrict__ bu
       for (int u = 0; u < U; ++u) v[u] = buf[idx[u] + (s >> 60)];
 #pragma unroll
       for (int u = 0; u < U; ++u) acc ^= v[u];
+    } else if (BYTES == 32) {
+      // a 32-byte record per lane PAIR and instruction: lanes 2i and 2i+1 read the two 16-byte halves of the same record
+      // (one sector per pair), halves exchanged across the pair afterwards -- against BYTES == 33: two instructions per lane
+      uint4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t pi = __shfl(idx[u], (int)(threadIdx.x & 63u & ~1u));   // the pair's record
+        v[u] = *reinterpret_cast<const uint4*>(buf + pi + 8 * ((s >> 62) & 1) + 4 * (threadIdx.x & 1u));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w ^ (uint32_t)__shfl_xor((int)v[u].x, 1);
+    } else if (BYTES == 33) {
+      uint4 v[U][2];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) v[u][c] = *reinterpret_cast<const uint4*>(buf + idx[u] + 8 * ((s >> 62) & 1) + 4 * c);
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= v[u][0].x ^ v[u][0].w ^ v[u][1].y ^ v[u][1].z;
     } else if (BYTES == 16) {
       uint4 v[U];
 #pragma unroll
@@ -84,7 +103,7 @@ static void run(const uint32_t* buf, uint64_t footprint, int blocks_per_cu, int 
     CHECK(hipEventElapsedTime(&ms, a, b));
     if (ms < best) best = ms;
   }
-  const double sectors = (double)grid.x * 256 * iters * U;
+  const double sectors = (double)grid.x * 256 * iters * U / (BYTES == 32 ? 2 : 1);
   printf("  %2d-byte loads, %d in flight per lane, %d blocks per CU: %7.3f ms  %6.1f G sectors/s = %5.2f TB/s of 64-byte requests\n", BYTES, U,
          blocks_per_cu, best, sectors / best / 1e6, sectors * 64 / best / 1e9);
   CHECK(hipEventDestroy(a));
@@ -115,6 +134,8 @@ int main(int argc, char** argv) {
     run<4, 8>(buf, mb << 20, 8, n_cu, d_out);
     run<64, 2>(buf, mb << 20, 8, n_cu, d_out);    // the radius search's 512-bit granules
     run<64, 4>(buf, mb << 20, 8, n_cu, d_out);
+    run<33, 4>(buf, mb << 20, 8, n_cu, d_out);    // "33" = a 32-byte record as two 16-byte loads of one lane (the k-NN verify today)
+    run<32, 8>(buf, mb << 20, 8, n_cu, d_out);    // "32" = the same record read by a lane pair in ONE instruction
   }
   CHECK(hipFree(buf));
   CHECK(hipFree(d_out));
