@@ -44,7 +44,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5shard", "knn_mih"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c1", "c2", "c5shard", "knn_mih", "sharded1dev"],
                     help="c3 = the headline (BASELINE configs[2]/[3]); the others are extra lines, same JSON shape")
     ap.add_argument("--db-size", dest="n", type=float, default=None, help="database size (total over all GPUs)")
     ap.add_argument("--bits", type=int, default=None)
@@ -57,9 +57,12 @@ def parse(argv=None):
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child run that measures roofline.traffic")
     ap.add_argument("--uniform-queries", action="store_true", help="workload knn_mih: uniform random queries (the worst case of the radius "
                     "loop: shells up to r ~ 8; answered through the cost-model switch to the verify kernel)")
-    ap.add_argument("--no-extras", action="store_true", help="default line only: skip the short qt=32 / c2 / knn_mih measurements (`extras`)")
+    ap.add_argument("--no-extras", action="store_true", help="default line only: skip the short measurements of the other shapes (`extras`)")
+    ap.add_argument("--approximate", action="store_true", help="workload knn_mih: VC_MODE_MIH_APPROX (search_worker.cc:93-157) instead of the exact loop")
+    ap.add_argument("--shards", type=int, default=8, help="workload sharded1dev: id-range shards behind vc_sharded_* (all on device 0)")
     args = ap.parse_args(argv)
-    d = {"c3": (1e9, 128, 8, 30), "c2": (1e8, 64, 1024, 20), "c5shard": (5e8, 256, 4096, 4), "knn_mih": (1e8, 128, 4096, 10)}[args.workload]
+    d = {"c3": (1e9, 128, 8, 30), "c1": (1 << 20, 64, 200, 50), "c2": (1e8, 64, 1024, 20), "c5shard": (5e8, 256, 4096, 4),
+         "knn_mih": (1e8, 128, 4096, 10), "sharded1dev": (1e9, 128, 8, 30)}[args.workload]
     if args.n is None:
         args.n = d[0]
     if args.bits is None:
@@ -125,7 +128,7 @@ def cpu_baseline_linear(args, n_total):
     return res
 
 
-def cpu_baseline_mih(args, m, kind, radius=None, clustered=False):
+def cpu_baseline_mih(args, m, kind, radius=None, clustered=False, approximate=False):
     """search_worker.cc:159-264 restated (oracle/vc_oracle.cc: enumerate_entry per rank, gather in rank order, master-side
     dedup + heap), one thread per table like `mpirun -n m` (run_distributed_search.py:12,74), in-memory buckets instead of
     a KV tier, on a bounded SAMPLE database: the probe count per query does not depend on N, only the bucket sizes do,
@@ -152,7 +155,7 @@ def cpu_baseline_mih(args, m, kind, radius=None, clustered=False):
             _, pr = mo.radius(q, radius, threads=threads)
             probes += pr
         else:
-            _, st = mo.find(q, args.k, stop_mult=min(m, 4), threads=threads)
+            _, st = mo.find(q, args.k, stop_mult=min(m, 4), threads=threads, approximate=approximate)
             probes += st.n_sub_reads_all
         done += 1
     dt = time.perf_counter() - t0
@@ -162,7 +165,8 @@ def cpu_baseline_mih(args, m, kind, radius=None, clustered=False):
                   "= one per table; %s; NOT scaled to the full size (bucket sizes grow with N, probes per query do not: %.0f "
                   "bucket gets per query)" % (done, dt, sample_n, t_build, threads,
                                               "search_R_neighbors shells 0..q per table, q = r/m for the first r mod m + 1 tables and r/m - 1 for the rest, + gather + dedup (search_worker.cc:222-264)"
-                                              if kind == "radius" else "SearchWorker::find exact loop (search_worker.cc:159-218)",
+                                              if kind == "radius" else ("SearchWorker::find approximate loop (search_worker.cc:93-157)" if approximate
+                                                                        else "SearchWorker::find exact loop (search_worker.cc:159-218)"),
                                               probes / max(done, 1)),
     }
 
@@ -240,6 +244,25 @@ def timed_steps(env, run_steps, steps):
     t1 = time.perf_counter()
     env.barrier()
     return res, env.max_over_ranks(t1 - t0)
+
+
+def step_times_ms(env, run_one, steps):
+    """Per-step device times (SURVEY.md 8d asks for a median next to the mean): an event between consecutive steps on the
+    launch stream, in a pass of its own AFTER the contract's timed region (whose clock stays two host timestamps around
+    K steps).  run_one(i) enqueues step i on torch's current stream."""
+    torch = env.torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    env.sync()
+    ev[0].record()
+    for i in range(steps):
+        run_one(i)
+        ev[i + 1].record()
+    env.sync()
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+
+def _median(v):
+    return float(np.median(np.asarray(v, dtype=np.float64))) if len(v) else None
 
 
 def measure_traffic(args, kernel_substr, fetch_mult=2.0, extra=()):
@@ -360,6 +383,24 @@ def run_headline(args, env, emit, backend_factory=None):
 
     (out, cnt), elapsed = timed_steps(env, run_steps, args.steps)
     tm = ss.backend.timing()  # HIP events on the launch stream, exactly the timed steps
+    out, cnt = out.clone(), cnt.clone()   # the passes below reuse the result buffers
+    step_ms = None
+    if env.cuda and backend_factory is None:
+        def one(i):
+            r = ss.search(dev_q[i % nb], k)
+            if (i + 1) % bucket == 0 or i + 1 == args.steps:
+                ss.flush()
+            return r
+        step_ms = step_times_ms(env, one, args.steps)
+        ss.backend.timing()
+    pre_extras = {}
+    if world == 1 and env.cuda and backend_factory is None and not args.no_extras and not force_exchange:
+        for name, fn in (("e2e_host", lambda: _extra_e2e_host(args, env, ss.backend.engine, host_q)),
+                         ("q1", lambda: _extra_q1(args, env, ss.backend.engine, dev_q))):
+            try:
+                pre_extras[name] = fn()
+            except Exception as ex:
+                pre_extras[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     ok = True
     if not args.no_check:
@@ -406,6 +447,7 @@ def run_headline(args, env, emit, backend_factory=None):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "median_ms_per_step": _median(step_ms) if step_ms else None,   # per-step events, a pass of its own after the timed region
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -438,8 +480,10 @@ def run_headline(args, env, emit, backend_factory=None):
         }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline_linear(args, n_total)
+        if pre_extras:
+            line["extras"] = dict(pre_extras)
         if world == 1 and env.cuda and backend_factory is None and not args.no_extras and n_total >= 10 ** 9:
-            line["extras"] = run_extras(args, env)
+            line.setdefault("extras", {}).update(run_extras(args, env))
         emit(line)
     return ok
 
@@ -504,6 +548,69 @@ def _add_sector_roofline(roof):
 # record carries them too (each: whole-call queries/s, the dominant kernel's average launch time and its algorithmic
 # bytes per launch; the full lines with cpu_baseline and PMC traffic are `--workload c2 / knn_mih`)
 # ---------------------------------------------------------------------------------------------------------------
+def _scan_fields(tm, steps=None):
+    """kernel time, algorithmic bytes and fraction of the HBM peak of the verify-kernel launches in `tm`"""
+    launches = max(tm.scan_launches, 1)
+    avg = tm.scan_ms / launches
+    alg = tm.scan_bytes / launches
+    ach = alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+    return {"kernel": "vc_scan_kernel", "kernel_avg_ms": avg, "kernel_launches": tm.scan_launches, "algorithmic_bytes_per_launch": alg,
+            "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS}
+
+
+def _extra_e2e_host(args, env, e, host_q, steps=12):
+    """What a SearchWorker::find caller sees (distributed_image_search.cc:62-85): the same 8-query step through
+    vc_search_knn with HOST pointers -- the queries' H2D copy and the rows' / counts' D2H copy inside the timed region,
+    every call synchronous (SURVEY.md 8d "end-to-end QPS including H2D of queries and D2H of Q x k x 8 B")."""
+    Q, k = host_q[0].shape[0], args.k
+    for i in range(3):
+        e.search_knn(host_q[i % len(host_q)], k)
+    e.timing()
+    times = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        t = time.perf_counter()
+        rows, cnt = e.search_knn(host_q[i % len(host_q)], k)
+        times.append((time.perf_counter() - t) * 1e3)
+    elapsed = time.perf_counter() - t0
+    tm = e.timing()
+    ok = bool(np.all(cnt == k)) and bool(np.all(rows[:, 1:] > rows[:, :-1]))
+    r = {"workload": "configs[2] step through vc_search_knn with host pointers: H2D of %d queries + D2H of %d x %d x 8 B rows inside the timed region, synchronous calls"
+                     % (Q, Q, k), "value": Q * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3,
+         "median_ms_per_step": _median(times), "results_check": "ok" if ok else "FAILED"}
+    r.update(_scan_fields(tm))
+    r["step_frac"] = r["algorithmic_bytes_per_launch"] / (elapsed / steps) / 1e9 / HBM_PEAK_GBPS   # bytes over the WHOLE step, PCIe included
+    return r
+
+
+def _extra_q1(args, env, e, dev_q, steps=12):
+    """SURVEY.md 8d "C3 at Q = 1": one query per database pass (the pure HBM-bound form of the verify kernel), device API"""
+    torch = env.torch
+    k = args.k
+    d_out = torch.empty((1, k), dtype=torch.int64, device=env.device)
+    d_cnt = torch.empty((1,), dtype=torch.int32, device=env.device)
+    st = torch.cuda.current_stream().cuda_stream
+    q1 = [dq[j:j + 1].contiguous() for dq in dev_q for j in (0, 1)]
+
+    def one(i):
+        e.search_knn_dev(q1[i % len(q1)].data_ptr(), 1, k, d_out.data_ptr(), d_cnt.data_ptr(), stream=st)
+
+    for i in range(3):
+        one(i)
+    env.sync()
+    e.timing()
+    _, elapsed = timed_steps(env, lambda c: [one(i) for i in range(c)], steps)
+    tm = e.timing()
+    res = d_out.cpu().numpy().view(np.uint64)
+    ok = bool(np.all(d_cnt.cpu().numpy() == k)) and bool(np.all(res[:, 1:] > res[:, :-1]))
+    times = step_times_ms(env, one, steps)
+    e.timing()
+    r = {"workload": "configs[2] at ONE query per pass (vc_search_knn_dev, nq = 1)", "value": steps / elapsed, "unit": "queries/s",
+         "ms_per_step": elapsed / steps * 1e3, "median_ms_per_step": _median(times), "results_check": "ok" if ok else "FAILED"}
+    r.update(_scan_fields(tm))
+    return r
+
+
 def _extra_qt32(args, env, steps=6):
     """the same verify kernel at 32 queries per pass: the throughput optimum (VALU-bound), where 8 per pass is the HBM-bound one"""
     torch = env.torch
@@ -528,84 +635,161 @@ def _extra_qt32(args, env, steps=6):
         tm = e.timing()
         res = d_out.cpu().numpy().view(np.uint64)
         ok = bool(np.all(d_cnt.cpu().numpy() == k)) and bool(np.all(res[:, 1:] > res[:, :-1])) and e.device_status() == 0
-    launches = max(tm.scan_launches, 1)
-    return {"workload": "configs[2] at 32 queries per pass (same engine and kernel; VALU-bound)", "value": Q * steps / elapsed,
-            "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "kernel": "vc_scan_kernel", "kernel_avg_ms": tm.scan_ms / launches,
-            "algorithmic_bytes_per_launch": tm.scan_bytes / launches, "results_check": "ok" if ok else "FAILED"}
+    r = {"workload": "configs[2] at 32 queries per pass (same engine and kernel; VALU-bound)", "value": Q * steps / elapsed,
+         "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "results_check": "ok" if ok else "FAILED"}
+    r.update(_scan_fields(tm))
+    return r
 
 
-def _extra_mih(args, env, kind, steps=6):
-    """kind 'c2': BASELINE configs[1] (64-bit, 1e8, all within 8, m = 2); 'knn_mih': exact top-100 through MIH on 1e8 clustered
-    128-bit codes -- the shapes of `--workload c2 / knn_mih`, a few steps each"""
+def _mih_fields(tm, bits, steps, kernel="mih_query_kernel"):
+    """time, algorithmic bytes and fraction of the HBM peak of the MIH query kernel's launches in `tm`"""
+    roof = _mih_roofline(tm, bits, kernel)
+    return {"kernel": kernel, "kernel_ms_per_step": tm.mih_ms / steps, "kernel_launches_per_step": tm.mih_launches / steps,
+            "kernel_avg_ms": roof.get("avg_launch_ms"),
+            "algorithmic_bytes_per_step": (roof.get("algorithmic_bytes_per_launch") or 0) * tm.mih_launches / steps,
+            "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch"),
+            "achieved_GBps": roof.get("achieved"), "frac": roof.get("frac"), "per_query": roof.get("per_query")}
+
+
+def _extra_c2(args, env, steps=6):
+    """BASELINE configs[1] (64-bit, 1e8, all within 8, m = 2) -- the shape of `--workload c2`, a few steps"""
     torch = env.torch
     from verticut_amd import engine as vc
-    n = 100_000_000
-    rng = np.random.default_rng(args.seed + (2 if kind == "c2" else 3))
-    if kind == "c2":
-        bits, m, Q, radius = 64, 2, 1024, 8
-        e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
-        e.add_synthetic(n, seed=args.seed)
-    else:
-        bits, m, Q, k = 128, 4, 4096, 100
-        e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
-        e.add_synthetic(n, seed=args.seed, kind=vc.SYNTH_CLUSTERED, n_centres=n // 1000, max_flips=11)
+    n, bits, m, Q, radius = 100_000_000, 64, 2, 1024, 8
+    rng = np.random.default_rng(args.seed + 2)
+    e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
     try:
+        e.add_synthetic(n, seed=args.seed)
         e.build_index()
-        host_q = [_near_queries(e, n, Q, bits, 8 if kind == "c2" else 4, rng) for _ in range(2)]
+        host_q = [_near_queries(e, n, Q, bits, 8, rng) for _ in range(2)]
         dq = [torch.from_numpy(h).to(env.device) for h in host_q]
         st = torch.cuda.current_stream().cuda_stream
-        if kind == "c2":
-            out_cap = Q * 64
-            d_out = torch.empty((out_cap,), dtype=torch.int64, device=env.device)
-            d_off = torch.empty((Q + 1,), dtype=torch.int64, device=env.device)
+        out_cap = Q * 64
+        d_out = torch.empty((out_cap,), dtype=torch.int64, device=env.device)
+        d_off = torch.empty((Q + 1,), dtype=torch.int64, device=env.device)
 
-            def run_steps(count):
-                for i in range(count):
-                    if e.search_radius_dev(dq[i % 2].data_ptr(), Q, radius, d_out.data_ptr(), out_cap, d_off.data_ptr(),
-                                           mode=vc.MODE_MIH_EXACT, stream=st) != vc.VC_OK:
-                        raise SystemExit("extras c2: results do not fit")
-        else:
-            d_out = torch.empty((Q, k), dtype=torch.int64, device=env.device)
-            d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
+        def one(i):
+            if e.search_radius_dev(dq[i % 2].data_ptr(), Q, radius, d_out.data_ptr(), out_cap, d_off.data_ptr(),
+                                   mode=vc.MODE_MIH_EXACT, stream=st) != vc.VC_OK:
+                raise SystemExit("extras c2: results do not fit")
 
-            def run_steps(count):
-                for i in range(count):
-                    e.search_knn_dev(dq[i % 2].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), mode=vc.MODE_MIH_EXACT, stream=st)
-
-        run_steps(3)
+        for i in range(3):
+            one(i)
         env.sync()
         e.timing()
-        _, elapsed = timed_steps(env, run_steps, steps)
+        _, elapsed = timed_steps(env, lambda c: [one(i) for i in range(c)], steps)
         tm = e.timing()
-        qh = host_q[(steps - 1) % 2][:16]
-        if kind == "c2":     # MIH == full scan on the last batch
-            off = d_off.cpu().numpy().view(np.uint64)
-            res = d_out.cpu().numpy().view(np.uint64)
-            lin = e.search_radius(qh, radius, mode=vc.MODE_LINEAR)
-            ok = all(np.array_equal(res[int(off[i]):int(off[i + 1])], lin[i]) for i in range(16))
-        else:                # exact MIH distances == full scan
-            lin, _ = e.search_knn(qh, k, mode=vc.MODE_LINEAR)
-            ok = bool(np.array_equal(d_out.cpu().numpy().view(np.uint64)[:16] >> np.uint64(32), lin >> np.uint64(32)))
+        qh = host_q[(steps - 1) % 2][:16]    # MIH == full scan on the last batch
+        off = d_off.cpu().numpy().view(np.uint64)
+        res = d_out.cpu().numpy().view(np.uint64)
+        lin = e.search_radius(qh, radius, mode=vc.MODE_LINEAR)
+        ok = all(np.array_equal(res[int(off[i]):int(off[i + 1])], lin[i]) for i in range(16))
+        times = step_times_ms(env, one, steps)
     finally:
         e.close()
-    roof = _mih_roofline(tm, bits)
-    return {"workload": ("configs[1]: 64-bit, 1e8 codes, all neighbours within 8, MIH m=2, 1024 queries per call" if kind == "c2" else
-                         "exact top-100 through MIH, 128-bit, 1e8 clustered codes, m=4, 4096 queries per call"),
-            "value": Q * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3,
-            "kernel": "mih_query_kernel",
-            "kernel_ms_per_step": tm.mih_ms / steps, "kernel_launches_per_step": tm.mih_launches / steps,
-            "algorithmic_bytes_per_step": (roof.get("algorithmic_bytes_per_launch") or 0) * tm.mih_launches / steps,
-            "per_query": roof.get("per_query"), "results_check": "ok" if ok else "FAILED"}
+    r = {"workload": "configs[1]: 64-bit, 1e8 codes, all neighbours within 8, MIH m=2, 1024 queries per call",
+         "value": Q * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "median_ms_per_step": _median(times),
+         "results_check": "ok" if ok else "FAILED"}
+    r.update(_mih_fields(tm, bits, steps))
+    return r
+
+
+def _extras_knn_mih(args, env, n, tag, legs, steps=6):
+    """SearchWorker::find through MIH on `n` clustered 128-bit codes (n/1000 centres, <= 11 flips; m = 4 x 32 bit): ONE engine
+    (data + index built once), one short measurement per leg:
+      exact    MIH_EXACT, 4096 near-duplicate queries per call            (search_worker.cc:159-218)
+      uniform  MIH_EXACT, 64 uniform random queries per call: the radius loop would walk to shell ~8; answered through the
+               cost-model switch by the verify kernel with the stop rule replayed
+      approx   MIH_APPROX, 4096 near-duplicate queries per call           (search_worker.cc:93-157)
+    Each leg: whole-call queries/s, kernel time, algorithmic bytes and `frac` of the HBM peak, a results check."""
+    torch = env.torch
+    from verticut_amd import engine as vc
+    bits, m, k = 128, 4, 100
+    rng = np.random.default_rng(args.seed + 3)
+    out = {}
+    t0 = time.perf_counter()
+    e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
+    try:
+        e.add_synthetic(n, seed=args.seed, kind=vc.SYNTH_CLUSTERED, n_centres=max(n // 1000, 1), max_flips=11)
+        e.build_index()
+        env.sync()
+        t_setup = time.perf_counter() - t0
+        st = torch.cuda.current_stream().cuda_stream
+        for leg in legs:
+            name = "knn_%s_%s" % ({"exact": "mih", "uniform": "uniform", "approx": "approx"}[leg], tag)
+            try:
+                Q = 64 if leg == "uniform" else 4096
+                mode = vc.MODE_MIH_APPROX if leg == "approx" else vc.MODE_MIH_EXACT
+                if leg == "uniform":
+                    host_q = [rng.integers(0, 256, size=(Q, bits // 8), dtype=np.uint8) for _ in range(2)]
+                else:
+                    host_q = [_near_queries(e, n, Q, bits, 4, rng) for _ in range(2)]
+                dq = [torch.from_numpy(h).to(env.device) for h in host_q]
+                d_out = torch.empty((Q, k), dtype=torch.int64, device=env.device)
+                d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
+
+                def one(i):
+                    e.search_knn_dev(dq[i % 2].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), mode=mode, stream=st)
+
+                nst = 4 if leg == "uniform" else steps
+                for i in range(3):
+                    one(i)
+                env.sync()
+                e.timing()
+                _, elapsed = timed_steps(env, lambda c: [one(i) for i in range(c)], nst)
+                tm = e.timing()
+                got = d_out.cpu().numpy().view(np.uint64)
+                cnt = d_cnt.cpu().numpy()
+                qh = host_q[(nst - 1) % 2][:16]
+                lin, _ = e.search_knn(qh, k, mode=vc.MODE_LINEAR)
+                if leg == "approx":   # k genuine items per query, ascending, never nearer than the exact answer
+                    ok = bool(np.all(cnt == k)) and bool(np.all(got[:, 1:] > got[:, :-1])) and \
+                        bool(np.all((got[:16] >> np.uint64(32)) >= (lin >> np.uint64(32))))
+                    for qi in range(2):
+                        for j in (0, k // 2, k - 1):
+                            code = e.get_code(int(got[qi, j] & np.uint64(0xFFFFFFFF)))
+                            ok = ok and int(np.unpackbits(np.bitwise_xor(code, qh[qi])).sum()) == int(got[qi, j] >> np.uint64(32))
+                else:                 # exact MIH distances == full scan
+                    ok = bool(np.array_equal(got[:16] >> np.uint64(32), lin >> np.uint64(32)))
+                e.timing()
+                times = step_times_ms(env, one, nst)
+                e.timing()
+                r = {"workload": {"exact": "exact top-100 through MIH (MIH_EXACT), 128-bit, %.3g clustered codes, m=4, 4096 near-duplicate queries per call",
+                                  "uniform": "MIH_EXACT with 64 UNIFORM random queries per call over %.3g clustered codes: shells 0..3 in the query kernel, then the "
+                                             "cost-model switch to the verify kernel, stop rule replayed",
+                                  "approx": "approximate top-100 through MIH (MIH_APPROX, stop at 20k candidates), 128-bit, %.3g clustered codes, m=4, 4096 queries per call"}[leg] % n,
+                     "value": Q * nst / elapsed, "unit": "queries/s", "ms_per_step": elapsed / nst * 1e3, "median_ms_per_step": _median(times),
+                     "results_check": "ok" if ok else "FAILED"}
+                r.update(_mih_fields(tm, bits, nst))
+                if tm.scan_launches:      # the switch sent queries to the verify kernel: that kernel dominates the step
+                    r["verify_kernel"] = _scan_fields(tm)
+                    r["verify_kernel"]["kernel_ms_per_step"] = tm.scan_ms / nst
+                    if leg == "uniform":
+                        r["mih_kernel_frac"] = r["frac"]
+                        r["frac"] = r["verify_kernel"]["frac"]
+                        r["kernel"] = "vc_scan_kernel (dominant: %.3f of %.3f ms per step) behind mih_query_kernel" % (tm.scan_ms / nst, elapsed / nst * 1e3)
+                if leg == "exact":
+                    r["setup_s"] = t_setup        # data generation + index build (+ {id, code} records)
+                out[name] = r
+            except Exception as ex:
+                out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    finally:
+        e.close()
+    return out
 
 
 def run_extras(args, env):
     out = {}
-    for name, fn in (("qt32", lambda: _extra_qt32(args, env)), ("c2_m2", lambda: _extra_mih(args, env, "c2")),
-                     ("knn_mih_1e8", lambda: _extra_mih(args, env, "knn_mih"))):
+    for name, fn in (("qt32", lambda: _extra_qt32(args, env)), ("c2_m2", lambda: _extra_c2(args, env))):
         try:
             out[name] = fn()
         except Exception as ex:   # an extra never takes the headline down with it; the failure is reported in its place
             out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    for n, tag, legs in ((100_000_000, "1e8", ("exact", "approx")), (1_000_000_000, "1e9", ("exact", "uniform"))):
+        try:
+            out.update(_extras_knn_mih(args, env, n, tag, legs))
+        except Exception as ex:
+            out["knn_mih_%s" % tag] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     return out
 
 
@@ -721,9 +905,14 @@ def run_knn_mih(args, env, emit):
     d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
     s = torch.cuda.current_stream().cuda_stream
 
+    mode = vc.MODE_MIH_APPROX if args.approximate else vc.MODE_MIH_EXACT
+
+    def one(i):
+        e.search_knn_dev(dev_q[i % 2].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), mode=mode, stream=s)
+
     def run_steps(count):
         for i in range(count):
-            e.search_knn_dev(dev_q[i % 2].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), mode=vc.MODE_MIH_EXACT, stream=s)
+            one(i)
 
     run_steps(max(args.warmup, 2))
     env.sync()
@@ -734,15 +923,24 @@ def run_knn_mih(args, env, emit):
     if not args.no_check:   # exact MIH == full scan on the distances (ids may differ among ties at the k-th distance)
         got = d_out.cpu().numpy().view(np.uint64)
         lin, _ = e.search_knn(host_q[(args.steps - 1) % 2][:16], k, mode=vc.MODE_LINEAR)
-        ok = bool(np.array_equal(got[:16] >> np.uint64(32), lin >> np.uint64(32)))
+        if args.approximate:   # k genuine items per query, ascending, never nearer than the exact answer
+            ok = bool(np.all(d_cnt.cpu().numpy() == k)) and bool(np.all(got[:, 1:] > got[:, :-1])) and \
+                bool(np.all((got[:16] >> np.uint64(32)) >= (lin >> np.uint64(32))))
+        else:
+            ok = bool(np.array_equal(got[:16] >> np.uint64(32), lin >> np.uint64(32)))
+    e.timing()
+    step_ms = step_times_ms(env, one, args.steps)
     e.close()
     line = {
-        "metric": "queries/sec (exact k-NN top-%d through MIH) on %d-bit clustered codes, %.3g DB; distances bit-exact vs linear scan" % (k, bits, n),
+        "metric": "queries/sec (%s k-NN top-%d through MIH) on %d-bit clustered codes, %.3g DB; %s" %
+                  ("approximate" if args.approximate else "exact", k, bits, n,
+                   "search_worker.cc:93-157 restated (parity in tests/)" if args.approximate else "distances bit-exact vs linear scan"),
         "value": Q * args.steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed / args.steps * 1e3, "median_ms_per_step": _median(step_ms), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {
-            "workload": "SearchWorker::find exact MIH: %d-bit codes, %.3g clustered codes (n/1000 centres, <= 11 flips), m=4 x 32-bit, top-%d" % (bits, n, k),
+            "workload": "SearchWorker::find %s MIH: %d-bit codes, %.3g clustered codes (n/1000 centres, <= 11 flips), m=4 x 32-bit, top-%d"
+                        % ("approximate" if args.approximate else "exact", bits, n, k),
             "n_codes": n, "bits": bits, "k": k, "queries_per_step": Q, "seed": args.seed,
             "query_kind": "uniform random (radius loop would need shells up to r ~ 8: answered by the verify kernel through the cost-model "
                           "switch, stop rule replayed)" if args.uniform_queries else "DB item with 0-4 random bit flips",
@@ -752,12 +950,89 @@ def run_knn_mih(args, env, emit):
         "results_check": "ok" if ok else "FAILED",
     }
     if not args.no_traffic:
-        t, how = measure_traffic(args, "mih_query_kernel", fetch_mult=1.0)
+        t, how = measure_traffic(args, "mih_query_kernel", fetch_mult=1.0,
+                                 extra=(["--approximate"] if args.approximate else []) + (["--uniform-queries"] if args.uniform_queries else []))
         line["roofline"]["traffic"], line["roofline"]["traffic_how"] = t, how + " (64-byte requests of 16-byte granule loads and gathers; uncorrected)"
         if line["roofline"].get("kernel") == "mih_query_kernel":
             _add_sector_roofline(line["roofline"])
     if args.cpu_seconds > 0:
-        line["cpu_baseline"] = cpu_baseline_mih(args, m, "knn", clustered=True)
+        line["cpu_baseline"] = cpu_baseline_mih(args, m, "knn", clustered=True, approximate=args.approximate)
+    emit(line)
+    return ok
+
+
+def run_c1(args, env, emit):
+    """BASELINE configs[0] / BASELINE.md row C1: linear_search.cc:39-64 over 64-bit codes, N = 2^20, the reference's 200-query
+    cap per run (distributed_image_search.cc:83-84), k = 100 -- the plumbing shape.  The GPU value stands next to BASELINE.md's
+    CPU-linear-1T and CPU-linear-allcores rows (cpu_baseline / cpu_baseline.allcores), which run on the WHOLE database here."""
+    torch = env.torch
+    from verticut_amd import engine as vc
+    n, bits, Q, k = int(args.n), args.bits, args.queries, args.k
+    rng = np.random.default_rng(args.seed + 1)
+    e = vc.Engine(bits, capacity=n, flags=vc.FLAG_LEAN_TIMING)      # default query tile (32): 200 queries = 7 passes over 8 MB
+    e.add_synthetic(n, seed=args.seed)
+    host_q = [rng.integers(0, 256, size=(Q, bits // 8), dtype=np.uint8) for _ in range(2)]
+    dev_q = [torch.from_numpy(h).to(env.device) for h in host_q]
+    d_out = torch.empty((Q, k), dtype=torch.int64, device=env.device)
+    d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def one(i):
+        e.search_knn_dev(dev_q[i % 2].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), stream=s)
+
+    def run_steps(count):
+        for i in range(count):
+            one(i)
+
+    run_steps(max(args.warmup, 2))
+    env.sync()
+    e.timing()
+    _, elapsed = timed_steps(env, run_steps, args.steps)
+    tm = e.timing()
+    ok = True
+    if not args.no_check:
+        res = d_out.cpu().numpy().view(np.uint64)
+        qh = host_q[(args.steps - 1) % 2]
+        ok = bool(np.all(d_cnt.cpu().numpy() == min(k, n))) and bool(np.all(res[:, 1:] > res[:, :-1]))
+        for qi in (0, Q // 2, Q - 1):
+            for j in (0, k - 1):
+                code = e.get_code(int(res[qi, j] & np.uint64(0xFFFFFFFF)))
+                ok = ok and int(np.unpackbits(np.bitwise_xor(code, qh[qi])).sum()) == int(res[qi, j] >> np.uint64(32))
+        ok = ok and e.device_status() == 0
+    e.timing()
+    step_ms = step_times_ms(env, one, args.steps)
+    # the host-pointer form of the same step (what the reference's driver loop does per query, distributed_image_search.cc:62-85)
+    t0 = time.perf_counter()
+    host_steps = max(2, min(args.steps, 10))
+    for i in range(host_steps):
+        e.search_knn(host_q[i % 2], k)
+    host_elapsed = time.perf_counter() - t0
+    e.close()
+    sf = _scan_fields(tm)
+    line = {
+        "metric": "queries/sec (k-NN top-%d, linear_search) on %d-bit codes, %d-code DB; bit-exact vs linear_search" % (k, bits, n),
+        "value": Q * args.steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "median_ms_per_step": _median(step_ms), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[0]: linear_search.cc brute-force k-NN, %d-bit codes, %d synthetic images (2^20), %d queries per "
+                        "run (the reference's cap), top-%d; the reference runs this shape on the CPU only -- its rows are cpu_baseline" % (bits, n, Q, k),
+            "n_codes": n, "bits": bits, "k": k, "queries_per_step": Q, "query_tile": 32, "query_kind": "uniform random", "seed": args.seed,
+            "api": "vc_search_knn_dev: queries and results resident in HBM",
+            "host_pointer_api": {"value": Q * host_steps / host_elapsed, "unit": "queries/s", "ms_per_step": host_elapsed / host_steps * 1e3,
+                                 "what": "the same step through vc_search_knn (H2D of the queries, D2H of the rows, synchronous)"},
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": sf["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sf["frac"], "traffic": None,
+            "kernel": "vc_scan_kernel", "launches": tm.scan_launches, "avg_launch_ms": sf["kernel_avg_ms"],
+            "algorithmic_bytes_per_launch": sf["algorithmic_bytes_per_launch"],
+            "note": "an 8 MB database lives in L2 / the Infinity Cache and a pass of 32 queries over it is launch- and VALU-bound: "
+                    "the HBM fraction of this plumbing shape says nothing about the kernel (the roofline run is configs[2])",
+        },
+        "results_check": "ok" if ok else "FAILED",
+    }
+    if args.cpu_seconds > 0:
+        line["cpu_baseline"] = cpu_baseline_linear(args, n)
     emit(line)
     return ok
 
@@ -848,6 +1123,10 @@ def main(argv=None, backend_factory=None, device_kind="cuda", dist_backend=None,
     try:
         if args.workload == "c3":
             ok = run_headline(args, env, emit, backend_factory=backend_factory)
+        elif args.workload == "c1":
+            ok = run_c1(args, env, emit)
+        elif args.workload == "sharded1dev":
+            ok = run_sharded1dev(args, env, emit)
         elif args.workload == "c2":
             ok = run_c2(args, env, emit)
         elif args.workload == "knn_mih":

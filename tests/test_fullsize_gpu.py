@@ -28,6 +28,38 @@ def _check_rows(e, q, rows, counts):
             assert int(np.unpackbits(code ^ q[i]).sum()) == int(r[j] >> SH)
 
 
+def test_config1_plumbing_64bit_1M(vc, oracle):
+    """BASELINE configs[0] at its stated shape: linear_search.cc:39-64 over 64-bit codes, N = 2^20,
+    the reference's 200-query cap (distributed_image_search.cc:83-84), k = 100.  Every row of the HIP scan equals the
+    oracle's canonical rows; the farthest-first order (what linear_search.cc:59-63 prints) carries the distance sequence
+    of the reference-order restatement; ids below the k-th distance are the reference heap's."""
+    n, bits, nq, k = 1 << 20, 64, 200, 100
+    rng = np.random.default_rng(1)
+    codes = oracle.gen_codes(n, bits, 34)
+    q = rng.integers(0, 256, size=(nq, bits // 8), dtype=np.uint8)
+    for i in range(0, nq, 4):                                # every fourth query is a near-duplicate of a stored image
+        q[i] = _flip(codes[int(rng.integers(0, n))], rng.choice(bits, size=int(rng.integers(0, 9)), replace=False), rng)
+    with vc.Engine(bits, capacity=n) as e:
+        e.add_synthetic(n, seed=34)
+        assert np.array_equal(e.get_code(n - 1), codes[n - 1])
+        rows, cnt = e.search_knn(q, k)
+        far, fcnt = e.search_knn(q, k, order=vc.ORDER_FARTHEST_FIRST)
+        with vc.Engine(bits, capacity=n) as h:               # the same records ingested from host memory (vc_add_codes)
+            h.add_codes(codes)
+            rows_h, _ = h.search_knn(q, k)
+    assert np.all(cnt == k) and np.all(fcnt == k)
+    assert np.array_equal(rows, rows_h)
+    with oracle.Pool() as pool:
+        exp, ecnt = pool.linear_knn(codes, q, k)
+    assert np.all(ecnt == k) and np.array_equal(rows, exp)
+    assert np.array_equal(far, rows[:, ::-1])
+    for i in range(0, nq, 8):                                # the reference-order restatement (std::priority_queue, strict >)
+        ref = oracle.linear_knn_ref(codes, q[i], k)
+        assert np.array_equal(far[i] >> SH, ref >> SH)       # same distances, farthest first
+        dk = rows[i, -1] >> SH
+        assert set(ref[(ref >> SH) < dk].tolist()) == set(rows[i][(rows[i] >> SH) < dk].tolist())
+
+
 def test_config3_top100_over_1e9_codes_128bit(vc, oracle):
     n, bits, k = 1_000_000_000, 128, 100
     rng = np.random.default_rng(3)

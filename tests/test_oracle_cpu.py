@@ -101,7 +101,9 @@ def test_linear_reference_order_vs_canonical(oracle, bits):
 
 
 def test_fewer_items_than_k(oracle):
-    codes = oracle.gen_codes(7, 128, 1)
+    # 64-bit codes / 16-bit substrings: seven uniform items sit ~32 bits apart, so the radius loop walks to shell ~7 of
+    # 65 536-key tables (with 32-bit substrings the same test enumerated 1.5e9 leaves: 116 s of the CPU suite)
+    codes = oracle.gen_codes(7, 64, 1)
     assert len(oracle.linear_knn_ref(codes, codes[0], 10)) == 7
     assert len(oracle.linear_knn(codes, codes[0], 10)) == 7
     mo = oracle.MihOracle(codes, 4, key_mode=1)
@@ -235,8 +237,11 @@ def _varint(v):
 
 
 def test_wire_encoding_matches_proto2(tmp_path):
-    """verticut_wire.hpp writes the bytes protobuf would for image_search.proto:3-27 (SURVEY.md appendix A.11);
-    the expected strings are assembled here independently from the proto2 wire rules."""
+    """verticut_wire.hpp writes the bytes protobuf would for image_search.proto:3-27.
+    Pinned two ways: tests/golden/wire_vectors.json holds field values and the bytes a REAL protobuf runtime serialized
+    them to (tests/golden/make_wire_vectors.py, google.protobuf in the authoring container) -- every vector must come out
+    of vc::wire::encode byte for byte and survive decode -> encode; and a few strings assembled here from the proto2
+    wire rules (kept from round 1: an independent second reading)."""
     import subprocess
     exe = tmp_path / "wire_test"
     subprocess.check_call(["g++", "-O1", "-std=c++14", "-o", str(exe), os.path.join(ROOT, "tests", "cpp", "wire_test.cc"),
@@ -250,6 +255,29 @@ def test_wire_encoding_matches_proto2(tmp_path):
     assert got["binarycode"] == (b"\x0a" + _varint(16) + code).hex()
     assert got["imagelist"] == b"".join(b"\x0a" + _varint(len(pair(i))) + pair(i) for i in (0, 1000000, 2000000)).hex()
     assert got["roundtrip"] == "ok"
+
+    with open(os.path.join(ROOT, "tests", "golden", "wire_vectors.json")) as f:
+        vec = json.load(f)
+    lines, want = [], []
+    for v in vec["id"]:
+        lines.append("id %d" % v["id"])
+        want.append(v["wire"])
+    for v in vec["binarycode"]:
+        lines.append("binarycode %s" % (v["code"] or "-"))
+        want.append(v["wire"])
+    for v in vec["hashindex"]:
+        lines.append("hashindex %d %d" % (v["table_id"], v["index"]))
+        want.append(v["wire"])
+    for v in vec["imagelist"]:
+        lines.append("imagelist %d %s" % (len(v["images"]), " ".join("%d %s" % (i, c or "-") for i, c in v["images"])))
+        want.append(v["wire"])
+    assert len(want) >= 60
+    res = subprocess.run([str(exe), "--vectors"], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout
+    rows = [l.split() for l in res.strip().splitlines()]
+    assert len(rows) == len(want)
+    for line, (enc, again), w in zip(lines, rows, want):
+        assert enc == (w or "-"), "%s: verticut_wire.hpp wrote %s, protobuf wrote %s" % (line, enc, w)
+        assert again == enc, "%s: decode -> encode changed the bytes" % line
 
 
 def test_oracle_threaded_find_and_radius_search(oracle):

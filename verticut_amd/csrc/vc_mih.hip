@@ -25,6 +25,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <sched.h>
 
 #include "vc_internal.hpp"
 #include "vc_mih.hpp"
@@ -2077,6 +2078,28 @@ hipError_t vc_launch_minsub_count(const uint64_t* cols, uint64_t stride, uint64_
   return hipSuccess;
 }
 
+// Host wait for a word a kernel publishes to mapped host memory (sequence number last).  The first ~30 us spin hot --
+// that is where the win over hipStreamSynchronize lies (~10 us per call) --, after that every probe is followed by a
+// pause instruction and, beyond 200 us, a sched_yield: a long launch (uniform queries, 1e9 shells) no longer burns a core,
+// and the G threads of the sharded host leg do not starve each other on a cgroup-limited host.  Gives up after 2 ms
+// (the caller then waits with hipStreamSynchronize): ADVICE round 3.
+template <class T>
+static bool poll_mapped_word(volatile T* flag, T expect) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spins = 0;; ++spins) {
+    if (*flag == expect) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return true;
+    }
+    if ((spins & 63u) != 63u) continue;
+    const auto dt = std::chrono::steady_clock::now() - t0;
+    if (dt > std::chrono::milliseconds(2)) return false;
+    if (dt > std::chrono::microseconds(200)) sched_yield();
+    else if (dt > std::chrono::microseconds(30))
+      for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
+  }
+}
+
 struct VcMihIndex {
   uint32_t W = 0, m = 0, sbits = 0, id_base = 0, flags = 0, n_cu = 0, cap = 0;
   uint64_t n = 0;
@@ -2933,11 +2956,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       // number last; polling that word returns ~10 us before hipStreamSynchronize does (VC_MIH_POLL=0: plain synchronise)
       bool landed = false;
       if (ix->h_ctr_dev && ix->knobs.mih_poll) {
-        volatile uint32_t* flag = h_ctr + 8;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spins = 0; !(landed = (*flag == ix->ctr_seq)); ++spins)
-          if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;   // long launches (or a fault): wait properly
-        std::atomic_thread_fence(std::memory_order_acquire);
+        landed = poll_mapped_word((volatile uint32_t*)(h_ctr + 8), (uint32_t)ix->ctr_seq);   // long launches (or a fault): wait properly
       }
       if (!ix->h_ctr_dev) MIH_CHECK(hipMemcpyAsync(h_ctr + 2, d_ctr + 2, 24, hipMemcpyDeviceToHost, s));
       if (!landed) MIH_CHECK(hipStreamSynchronize(s));
@@ -3236,11 +3255,7 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
     // returns while the last copy-out kernel may still run (results are in stream order; host readers copy behind it)
     bool landed = false;
     if (poll && nq) {
-      volatile unsigned long long* flag = wk->h_tot + 2;
-      const auto t0 = std::chrono::steady_clock::now();
-      for (uint32_t spins = 0; !(landed = (*flag == wk->seq)); ++spins)
-        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-      std::atomic_thread_fence(std::memory_order_acquire);
+      landed = poll_mapped_word((volatile unsigned long long*)(wk->h_tot + 2), (unsigned long long)wk->seq);
     }
     if (!landed) {
       R_CHECK(hipMemcpyAsync(wk->h_tot, d_tot, 16, hipMemcpyDeviceToHost, s));

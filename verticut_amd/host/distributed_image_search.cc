@@ -16,7 +16,8 @@
 //                < 0: read queries from query_file (raw codes, at most 200: :83-84) and print the
 //                "Averate result" line of :87-93
 // VC_SHARDS=G (and optionally VC_DEVICES=0,1,..) spreads the records over G GPUs of the node (vc_sharded_*), which is what
-// `mpirun -n 4` + the KV tier did for the reference.  Set VC_PRINT_RESULTS=1 to print the "id : dist" lines for file queries too; VC_REF_QUIRKS=1 reproduces the reference's
+// `mpirun -n 4` + the KV tier did for the reference; the printed n_sub_reads / n_local_reads are then SUMS over the shards and
+// radius the widest shard's (every shard stops by its own rule), not one SearchWorker's figures.  Set VC_PRINT_RESULTS=1 to print the "id : dist" lines for file queries too; VC_REF_QUIRKS=1 reproduces the reference's
 // behaviour for substrings < 32 bit / fewer than 4 tables (sign-extended keys, literal-4 stop rule).
 // ============================================================================
 #include <stdio.h>

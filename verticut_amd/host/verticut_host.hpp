@@ -228,19 +228,31 @@ class ShardedEngine : public Backend {
 };
 
 // VC_SHARDS=G [VC_DEVICES=0,1,...]: the drivers' switch from one engine to the sharded store (no argv position is free for
-// it: run_distributed_search.py:74-79 fixes them all)
+// it: run_distributed_search.py:74-79 fixes them all).  G = 1 (or unset) is the one-GPU Engine -- a one-shard store would
+// only add an exchange, a merge and copies --; anything that is not a number in 1..VC_MAX_SHARDS is refused, not guessed at.
+// Under VC_SHARDS the printed n_sub_reads / n_local_reads are SUMS over the shards and radius the widest shard's (every
+// shard stops by its own rule, verticut_gpu.h), not the figures of one SearchWorker over the whole database.
 inline Backend* make_backend(uint32_t bits, uint32_t n_tables, uint64_t capacity, uint32_t flags) {
   const char* g = getenv("VC_SHARDS");
-  const uint32_t shards = g ? (uint32_t)atoi(g) : 0;
-  if (shards == 0) return new Engine(bits, n_tables, capacity, flags);
+  long shards = 1;
+  if (g && *g) {
+    char* end = nullptr;
+    shards = strtol(g, &end, 10);
+    if (end == g || *end != '\0' || shards < 1 || shards > VC_MAX_SHARDS)
+      throw EngineError(VC_ERR_INVALID, std::string("VC_SHARDS must be a number in 1..") + std::to_string(VC_MAX_SHARDS) + ", got '" + g + "'");
+  }
+  if (shards <= 1) return new Engine(bits, n_tables, capacity, flags);
   std::vector<int> devices;
   if (const char* d = getenv("VC_DEVICES"))
     for (const char* p = d; *p;) {
-      devices.push_back(atoi(p));
-      while (*p && *p != ',') ++p;
-      if (*p == ',') ++p;
+      char* end = nullptr;
+      const long v = strtol(p, &end, 10);
+      if (end == p || v < 0 || (*end != ',' && *end != '\0'))
+        throw EngineError(VC_ERR_INVALID, std::string("VC_DEVICES must be comma-separated device ordinals, got '") + d + "'");
+      devices.push_back((int)v);
+      p = *end == ',' ? end + 1 : end;
     }
-  return new ShardedEngine(bits, n_tables, capacity, shards, devices, flags);
+  return new ShardedEngine(bits, n_tables, capacity, (uint32_t)shards, devices, flags);
 }
 
 // BaseProxy over the resident index.  put(ID, BinaryCode) appends a record (ids must arrive in order, as
