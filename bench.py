@@ -16,7 +16,9 @@ reference path timed on this host on a bounded sample).
         bench.py --gpus N --steps K --warmup W
     python bench.py --workload c2                 # BASELINE configs[1]: 64-bit, 1e8 codes, MIH radius-8 search (m = 2; m = 4 as a variant)
     python bench.py --workload c5shard            # one GPU's share of configs[4]: 256-bit, 5e8 codes, 4096 queries per pass
-    python bench.py --workload knn_mih            # exact top-100 through MIH on 1e8 clustered 128-bit codes
+    python bench.py --workload knn_mih            # exact top-100 through MIH on 1e8 clustered 128-bit codes (--approximate, --uniform-queries)
+    python bench.py --workload c1                 # BASELINE configs[0]: 64-bit, 2^20 codes, 200 queries, linear (plumbing shape + CPU rows)
+    python bench.py --workload sharded1dev        # 1e9 codes as 8 id-range shards on one device through vc_sharded_search_knn_dev
 """
 import argparse
 import json
@@ -1033,6 +1035,102 @@ def run_c1(args, env, emit):
     }
     if args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline_linear(args, n)
+    emit(line)
+    return ok
+
+
+def run_sharded1dev(args, env, emit):
+    """BASELINE configs[3]'s shard arithmetic behind the C ABI in ONE process on ONE device: the 1e9-code database as
+    `--shards` id-range shards through vc_sharded_search_knn_dev (queries, rows and counts resident in HBM, one stream).
+    Reported: ms per batch through the sharded layer against (a) the sum of the shards' verify-kernel times and (b) the
+    same shard engines driven back to back WITHOUT the layer (vc_search_knn_dev per shard, no exchange, no merge) -- the
+    difference to (b) is what the layer itself costs per batch (its host work, the merge launch, the slot bookkeeping)."""
+    torch = env.torch
+    from verticut_amd import engine as vc
+    n, bits, Q, k, G = int(args.n), args.bits, args.queries, args.k, args.shards
+    rng = np.random.default_rng(args.seed + 1)
+    tsample = int(os.environ.get("VC_BENCH_TIMING_SAMPLE", "8"))     # an event pair per verify launch costs ~8 us: time every 8th
+    s = vc.ShardedEngine(bits, capacity=n, n_shards=G, devices=[0], query_tile=Q, timing_sample=tsample)
+    s.add_synthetic(n, seed=args.seed)
+    shards = [s.shard(g) for g in range(G)]
+    host_q = [rng.integers(0, 256, size=(Q, bits // 8), dtype=np.uint8) for _ in range(4)]
+    dev_q = [torch.from_numpy(h).to(env.device) for h in host_q]
+    d_out = torch.empty((Q, k), dtype=torch.int64, device=env.device)
+    d_cnt = torch.empty((Q,), dtype=torch.int32, device=env.device)
+    raw = torch.empty((G, Q, k), dtype=torch.int64, device=env.device)
+    rcnt = torch.empty((G, Q), dtype=torch.int32, device=env.device)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def one(i):
+        s.search_knn_dev(dev_q[i % 4].data_ptr(), Q, k, d_out.data_ptr(), d_cnt.data_ptr(), stream=st)
+
+    def bare(i):          # the floor: the same engines, the same stream, no sharded layer
+        for g, e in enumerate(shards):
+            e.search_knn_dev(dev_q[i % 4].data_ptr(), Q, k, raw[g].data_ptr(), rcnt[g].data_ptr(), stream=st)
+
+    for i in range(max(args.warmup, 8)):
+        one(i)
+    env.sync()
+    for e in shards:
+        e.timing()
+    _, elapsed = timed_steps(env, lambda c: [one(i) for i in range(c)], args.steps)
+    tms = [e.timing() for e in shards]
+    res = d_out.cpu().numpy().view(np.uint64).copy()
+    cnt = d_cnt.cpu().numpy().copy()
+    step_ms = step_times_ms(env, one, args.steps)
+    # host time spent ENQUEUEING a batch (the call returns before the device has finished)
+    env.sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one(i)
+    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    env.sync()
+    for i in range(4):
+        bare(i)
+    env.sync()
+    _, bare_elapsed = timed_steps(env, lambda c: [bare(i) for i in range(c)], args.steps)
+    ok = True
+    if not args.no_check:    # the sharded rows == merge of the bare shard rows of the same batch, distances recomputed from the stored codes
+        qi = (args.steps - 1) % 4
+        bare(qi)
+        merged = torch.empty((Q, k), dtype=torch.int64, device=env.device)
+        vc.merge_topk_dev(raw.data_ptr(), G, Q, k, merged.data_ptr(), None, stream=st)
+        env.sync()
+        ok = bool(np.array_equal(res, merged.cpu().numpy().view(np.uint64))) and bool(np.all(cnt == k)) and bool(np.all(res[:, 1:] > res[:, :-1]))
+        for j in (0, k - 1):
+            code = s.get_code(int(res[0, j] & np.uint64(0xFFFFFFFF)))
+            ok = ok and int(np.unpackbits(np.bitwise_xor(code, host_q[qi][0])).sum()) == int(res[0, j] >> np.uint64(32))
+    for e in shards:
+        e.close()
+    s.close()
+    scan_avgs = [t.scan_ms / max(t.scan_launches, 1) for t in tms]
+    sum_scan = float(sum(scan_avgs))
+    ms = elapsed / args.steps * 1e3
+    bare_ms = bare_elapsed / args.steps * 1e3
+    ach = n * (bits // 8) / (sum_scan * 1e-3) / 1e9 if sum_scan > 0 else 0.0
+    line = {
+        "metric": METRIC, "value": Q * args.steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "median_ms_per_step": _median(step_ms), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[3]'s partition on ONE device: %d-bit codes, %.3g-code DB as %d id-range shards behind vc_sharded_search_knn_dev "
+                        "(one process, one stream), top-%d, per-shard top-k merged on the device" % (bits, n, G, k),
+            "n_codes": n, "bits": bits, "k": k, "queries_per_step": Q, "shards": G, "query_kind": "uniform random", "seed": args.seed,
+            "api": "vc_sharded_search_knn_dev: queries, rows and counts resident in HBM",
+        },
+        "sharded_layer": {
+            "ms_per_batch": ms, "sum_of_shard_scan_kernel_ms": sum_scan, "shard_scan_kernel_ms": scan_avgs,
+            "same_engines_without_the_layer_ms": bare_ms, "layer_overhead_us": (ms - bare_ms) * 1e3,
+            "around_the_verify_kernels_us": (ms - sum_scan) * 1e3, "host_enqueue_ms_per_batch": host_issue_ms,
+            "what": "layer_overhead_us = ms_per_batch - the same %d shard engines driven back to back on the same stream without exchange / merge; "
+                    "around_the_verify_kernels_us also holds every shard's bootstrap / select / recover launches" % G,
+        },
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "vc_scan_kernel", "launches": sum(t.scan_launches for t in tms), "avg_launch_ms": sum_scan / max(G, 1),
+                     "algorithmic_bytes_per_launch": n * (bits // 8) / max(G, 1),
+                     "note": "all %d shards' verify launches of a batch together read the database once: achieved = N x B/8 / their summed time" % G},
+        "results_check": "ok" if ok else "FAILED",
+    }
     emit(line)
     return ok
 

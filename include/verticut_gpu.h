@@ -193,6 +193,11 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
  * recovery gives up (see vc_device_status) a query reports d_counts[i] == UINT32_MAX with an upper-bound row. */
 int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode,
                       uint64_t* d_out, uint32_t* d_counts, void* stream);
+/* Same, plus SearchWorker::get_stat (search_worker.cc:24-30) for callers that stay on the device: d_stats (device
+ * memory, nq records, may be NULL) is written by a kernel in stream order -- no host read-back, no extra wait.
+ * LINEAR: n_candidates = records scanned, everything else 0.  n_results = d_counts[i]. */
+int vc_search_knn_dev_stats(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode,
+                            uint64_t* d_out, uint32_t* d_counts, vc_query_stats* d_stats, void* stream);
 /* All items within full Hamming distance <= radius of each query (BASELINE config 2; built from
  * search_R_neighbors shells 0..radius/m, search_worker.cc:222-227).  mode LINEAR or MIH_EXACT.
  * out_offsets: nq+1 entries; results of query i at out[out_offsets[i] .. out_offsets[i+1]),
@@ -268,6 +273,19 @@ int vc_sharded_get_bucket(vc_sharded* h, uint32_t table, uint32_t index, uint32_
 /* SearchWorker::find / linear_search for a batch over all shards; arguments as vc_search_knn */
 int vc_sharded_search_knn(vc_sharded* h, const void* queries, uint32_t nq, uint32_t k, uint32_t mode, uint32_t order,
                           uint64_t* out, uint32_t* counts, vc_query_stats* stats);
+/* Device-resident, stream-ordered form: d_queries (nq*bits/8 bytes), d_out (nq*k), d_counts (nq, may be NULL) and
+ * d_stats (nq records, may be NULL) are device memory on the ROOT device (vc_sharded_root_device: the first shard's),
+ * `stream` a stream of that device (NULL = its null stream, VC_STREAM_OWN = the handle's own).  The queries reach every
+ * other device by one peer copy, the shards of a device run one after the other on that device's stream and the devices
+ * concurrently, rows + counts + statistics of a shard travel as one slot (one peer copy per remote shard or one grouped
+ * ncclAllGather), the merge kernel reduces the shards' overflow flags on the device (a row whose shard-side recovery
+ * gave up reports d_counts[i] == UINT32_MAX, exactly as vc_search_knn_dev does) and a small kernel the statistics.
+ * LINEAR: nothing is waited for on the host -- results are valid in stream order.  MIH modes: as in vc_search_knn_dev the
+ * host waits inside every shard for its query kernel (lanes of different devices then run on host threads).
+ * replaces: search_worker.cc:99-101,177,207 + mpi_coordinator.cc:34-69 for callers that keep the batch in HBM. */
+int vc_sharded_search_knn_dev(vc_sharded* h, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode,
+                              uint64_t* d_out, uint32_t* d_counts, vc_query_stats* d_stats, void* stream);
+int vc_sharded_root_device(const vc_sharded* h, int* device);
 /* borrow shard g's engine (bucket views, timing, files); its id range is [*first_id, *first_id + *n_ids) */
 int vc_sharded_shard(vc_sharded* h, uint32_t shard, vc_engine** e, uint64_t* first_id, uint64_t* n_ids);
 

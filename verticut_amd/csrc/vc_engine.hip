@@ -867,6 +867,25 @@ static int check_knn_args(vc_engine* e, const void* q, uint32_t nq, uint32_t k, 
 
 int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode, uint64_t* d_out,
                       uint32_t* d_counts, void* stream) {
+  return vc_search_knn_dev_stats(e, d_queries, nq, k, mode, d_out, d_counts, nullptr, stream);
+}
+
+}  // extern "C"
+
+// get_stat of a linear scan (vc_search_knn's host loop writes the same): every item was a candidate, nothing was probed
+__global__ void vc_linear_stats_kernel(const uint32_t* __restrict__ cnt, uint32_t nq, uint64_t n, vc_query_stats* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  vc_query_stats o{};
+  o.n_results = cnt[i];
+  o.n_candidates = n;
+  out[i] = o;
+}
+
+extern "C" {
+
+int vc_search_knn_dev_stats(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode, uint64_t* d_out,
+                            uint32_t* d_counts, vc_query_stats* d_stats, void* stream) {
   int rc = check_knn_args(e, d_queries, nq, k, mode);
   if (rc) return rc;
   if (!d_out) return VC_ERR_INVALID;
@@ -874,13 +893,18 @@ int vc_search_knn_dev(vc_engine* e, const void* d_queries, uint32_t nq, uint32_t
   hipStream_t saved = e->stream;
   e->stream = stream == VC_STREAM_OWN ? e->own_stream : (hipStream_t)stream;   // NULL = the HIP null stream
   if ((rc = grow(e, &e->d_cnt, &e->cnt_bytes, (size_t)nq * 8))) { e->stream = saved; return rc; }
+  uint32_t* cnt = d_counts ? d_counts : e->d_cnt;
   timing_begin(e);
   if (mode == VC_MODE_LINEAR) {
-    rc = linear_batch(e, (const uint64_t*)d_queries, nq, k, d_out, d_counts ? d_counts : e->d_cnt);
+    rc = linear_batch(e, (const uint64_t*)d_queries, nq, k, d_out, cnt);
+    if (rc == VC_OK && d_stats) {
+      hipLaunchKernelGGL(vc_linear_stats_kernel, dim3((nq + 255) / 256), dim3(256), 0, e->stream, (const uint32_t*)cnt, nq, e->n, d_stats);
+      if (hipGetLastError() != hipSuccess) rc = fail(e, VC_ERR_HIP, "vc_linear_stats_kernel launch failed");
+    }
   } else {
     const VcMihScanFallback fb{mih_scan_fallback, e, e->n_cu};
     rc = vc_mih_search(e->mih, e->d_cols, e->stride, e->n, (const uint64_t*)d_queries, nq, k, mode == VC_MODE_MIH_APPROX,
-                       d_out, d_counts ? d_counts : e->d_cnt, nullptr, e->stream, &e->err, &fb);
+                       d_out, cnt, nullptr, e->stream, &e->err, &fb, d_stats);
   }
   timing_end(e);
   e->stream = saved;

@@ -97,3 +97,6 @@ hipError_t vc_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint64_t n,
 // n_lists x [nq][k] sorted lists -> merged top-k
 hipError_t vc_launch_select_lists(const uint64_t* d_lists, uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* d_out,
                                   uint32_t* d_out_count, hipStream_t s);
+// the same over the gathered shard slots of vc_sharded_* (rows + counts per slot; a flagged shard row flags the merged row)
+hipError_t vc_launch_select_slots(const uint64_t* d_base, uint64_t slot_words, uint32_t cnt_off_words, uint32_t n_lists, uint32_t nq,
+                                  uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s);

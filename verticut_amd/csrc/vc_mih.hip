@@ -2886,9 +2886,25 @@ static uint32_t inblock_last_shell(uint32_t S, uint32_t m, uint64_t budget, uint
 #define MQ_KNN_BUDGET 600000ull        // probes per query run inside mih_query_kernel (32-bit substrings, m = 4: shells 0..4)
 #define MQ_RADIUS_BUDGET 4000000ull
 
+// SearchWorker::get_stat for callers that stay on the device (vc_search_knn_dev_stats): the tile's statistics arrays ->
+// vc_query_stats records in device memory, n_results from the rows' counts.  One thread per query.
+__global__ void mih_stats_export_kernel(MihState st, const uint32_t* __restrict__ cnt, uint32_t qt, vc_query_stats* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= qt) return;
+  vc_query_stats o;
+  o.radius = st.radius[i];
+  o.n_results = cnt[i];
+  o.n_main_reads = 0;
+  o.n_sub_reads = st.sub[i];
+  o.n_local_reads = st.loc[i];
+  o.n_candidates = st.seen[i];
+  out[i] = o;
+}
+
 int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint64_t n, const uint64_t* d_q, uint32_t nq,
-                  uint32_t k, bool approximate, uint64_t* d_out, uint32_t* d_cnt, vc_query_stats* stats, hipStream_t s,
-                  std::string* err, const VcMihScanFallback* fb) {
+                  uint32_t k, bool approximate, uint64_t* d_out, uint32_t* d_cnt, vc_query_stats* host_stats, hipStream_t s,
+                  std::string* err, const VcMihScanFallback* fb, vc_query_stats* d_stats) {
+  const bool stats = host_stats != nullptr || d_stats != nullptr;   // the cost model prices the statistics pass either way
   if (n != ix->n) {
     if (err) *err = "index is stale: codes were added after vc_build_index()";
     return VC_ERR_STATE;
@@ -2991,7 +3007,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
             VcMihScanTarget tgt{st.ring, cap, st.count, st.radius, st.seen, st.sub, st.loc};
             MIH_CHECK(hipMemsetAsync(d_ctr, 0, 4, s));
             // unresolved queries (ring overflow, too many ties) rejoin the radius loop: appended behind the kept ones
-            rc = fb->fn(fb->ctx, d_q + (size_t)q0 * ix->W, nxt, n_scan, k, stop_mult, tgt, stats != nullptr, redo + n_keep, d_ctr, s);
+            rc = fb->fn(fb->ctx, d_q + (size_t)q0 * ix->W, nxt, n_scan, k, stop_mult, tgt, stats, redo + n_keep, d_ctr, s);
             if (rc) {
               if (err) *err = "scan fallback of the exact k-NN loop failed";
               return rc;
@@ -3020,7 +3036,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
         if (est_mih > est_scan || ix->knobs.mih_switch == 2) {
           VcMihScanTarget tgt{st.ring, cap, st.count, st.radius, st.seen, st.sub, st.loc};
           MIH_CHECK(hipMemsetAsync(d_ctr, 0, 8, s));
-          rc = fb->fn(fb->ctx, d_q + (size_t)q0 * ix->W, cur, n_cur, k, stop_mult, tgt, stats != nullptr, nxt, d_ctr, s);
+          rc = fb->fn(fb->ctx, d_q + (size_t)q0 * ix->W, cur, n_cur, k, stop_mult, tgt, stats, nxt, d_ctr, s);
           if (rc) {
             if (err) *err = "scan fallback of the exact k-NN loop failed";
             return rc;
@@ -3081,7 +3097,11 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
                          d_out + (size_t)q0 * k, d_cnt + q0);
       MIH_CHECK(hipGetLastError());
     }
-    if (stats) {
+    if (d_stats) {
+      hipLaunchKernelGGL(mih_stats_export_kernel, dim3((qt + 255) / 256), dim3(256), 0, s, st, (const uint32_t*)(d_cnt + q0), qt, d_stats + q0);
+      MIH_CHECK(hipGetLastError());
+    }
+    if (host_stats) {
       std::vector<unsigned long long> seen(qt), sub(qt), loc(qt);
       std::vector<uint32_t> rad(qt);
       MIH_CHECK(hipMemcpyAsync(seen.data(), st.seen, qt * 8, hipMemcpyDeviceToHost, s));
@@ -3090,7 +3110,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       MIH_CHECK(hipMemcpyAsync(rad.data(), st.radius, qt * 4, hipMemcpyDeviceToHost, s));
       MIH_CHECK(hipStreamSynchronize(s));
       for (uint32_t i = 0; i < qt; ++i) {
-        vc_query_stats& o = stats[q0 + i];
+        vc_query_stats& o = host_stats[q0 + i];
         o.radius = rad[i];
         o.n_results = 0;
         o.n_main_reads = 0;

@@ -64,9 +64,10 @@ hipError_t vc_launch_minsub_count(const uint64_t* cols, uint64_t stride, uint64_
                                   const uint32_t* d_radius, unsigned long long* d_seen, uint32_t n_cu, hipStream_t s);
 
 // d_q [nq][W]; d_out [nq][k] ascending INF-padded; d_cnt [nq]; stats (host, may be null) filled after a sync.
+// d_stats (device, may be null): the same records written by a kernel in stream order, no host wait for them.
 int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint64_t n, const uint64_t* d_q, uint32_t nq,
                   uint32_t k, bool approximate, uint64_t* d_out, uint32_t* d_cnt, vc_query_stats* stats, hipStream_t s,
-                  std::string* err, const VcMihScanFallback* fb = nullptr);
+                  std::string* err, const VcMihScanFallback* fb = nullptr, vc_query_stats* d_stats = nullptr);
 int vc_mih_bucket(VcMihIndex* ix, uint32_t table, uint32_t index, std::vector<uint32_t>* local_ids, hipStream_t s,
                   std::string* err);
 int vc_mih_bitmap_test(VcMihIndex* ix, uint32_t table, uint32_t index, int* bit, hipStream_t s, std::string* err);

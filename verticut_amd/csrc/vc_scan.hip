@@ -661,6 +661,25 @@ struct VcListsSrc {
   }
 };
 
+// The gathered per-shard results of vc_sharded_*: shard g's slot starts g * slot_words words into `base` and holds its
+// [nq][k] rows followed, cnt_off (64-bit) words in, by its [nq] counts.  A shard that flags a row (count UINT32_MAX: its ring
+// overflowed and the device-side recovery gave up) flags the merged row -- the overflow flags are reduced HERE, on the
+// device, instead of a count read-back and a host wait per shard.
+struct VcSlotsSrc {
+  const uint64_t* base;
+  uint64_t slot_words;
+  uint32_t cnt_off, n_lists, nq, k;
+  __device__ uint32_t slot(uint32_t b) const { return b; }
+  __device__ uint64_t bound(uint32_t) const { return VC_PACK_INF; }
+  __device__ bool overflowed(uint32_t q) const {
+    for (uint32_t g = 0; g < n_lists; ++g)
+      if (((const uint32_t*)(base + (uint64_t)g * slot_words + cnt_off))[q] == 0xFFFFFFFFu) return true;
+    return false;
+  }
+  __device__ uint32_t size(uint32_t) const { return n_lists * k; }
+  __device__ uint64_t get(uint32_t q, uint32_t i) const { return base[(uint64_t)(i / k) * slot_words + (uint64_t)q * k + (i % k)]; }
+};
+
 #define VC_SEL_THREADS 1024
 #define VC_RANK_SORT_MAX 1024u
 
@@ -1427,6 +1446,14 @@ hipError_t vc_launch_recover(const uint64_t* cols, uint64_t stride, uint64_t n, 
       return hipErrorInvalidValue;
   }
 #undef VC_REC_CASE
+  return hipGetLastError();
+}
+
+hipError_t vc_launch_select_slots(const uint64_t* d_base, uint64_t slot_words, uint32_t cnt_off_words, uint32_t n_lists, uint32_t nq,
+                                  uint32_t k, uint64_t* d_out, uint32_t* d_out_count, hipStream_t s) {
+  if (nq == 0) return hipSuccess;
+  VcSlotsSrc src{d_base, slot_words, cnt_off_words, n_lists, nq, k};
+  hipLaunchKernelGGL((vc_select_kernel<VcSlotsSrc>), dim3(nq), dim3(VC_SEL_THREADS), 0, s, src, k, d_out, d_out_count);
   return hipGetLastError();
 }
 

@@ -68,13 +68,18 @@ struct RcclApi {
   }
 };
 
-struct ShardBuf {
-  void* q = nullptr;        size_t q_bytes = 0;     // the batch's queries on the shard's device
-  uint64_t* top = nullptr;  size_t top_bytes = 0;   // [nq][k] per-shard top-k
-  uint32_t* cnt = nullptr;  size_t cnt_bytes = 0;
-  uint64_t* recv = nullptr; size_t recv_bytes = 0;  // RCCL: [G][nq][k] all-gathered rows on this device
-  hipStream_t stream = nullptr;
-  hipEvent_t done = nullptr;
+// One lane per distinct device: the shards that live there run ONE AFTER THE OTHER on the lane's stream -- at most one
+// persistent-grid kernel sequence per GPU (the recovery kernel's grid barrier needs its whole grid resident; a neighbour
+// shard's full-chip verify grid on another stream could keep it off the CUs for seconds: ADVICE round 3) -- while the
+// lanes, i.e. the devices, run concurrently.  The root device's lane runs on the caller's stream.
+struct Lane {
+  int dev = 0;
+  std::vector<uint32_t> shards;
+  hipStream_t stream = nullptr;                   // own stream (the root lane uses the caller's)
+  hipEvent_t done = nullptr;                      // behind the lane's last shard of a batch
+  void* q = nullptr;        size_t q_bytes = 0;   // the batch's queries on this device (peer copy from the root)
+  uint64_t* gath = nullptr; size_t gath_bytes = 0;   // [G][slot]: shard g's rows | counts | statistics at slot g; on the root
+                                                     // (and, with RCCL, everywhere) the gathered results of all shards
 };
 
 }  // namespace
@@ -86,12 +91,16 @@ struct vc_sharded {
   std::vector<vc_engine*> eng;
   std::vector<int> dev;                 // device of shard g
   std::vector<uint64_t> lo, hi;         // ids [lo, hi) relative to cfg.engine.id_base
-  std::vector<ShardBuf> buf;
+  std::vector<Lane> lanes;
+  std::vector<uint32_t> lane_of;        // shard -> lane
+  uint32_t root_lane = 0;
   int root = 0;                         // device that merges
-  hipStream_t root_stream = nullptr;
-  uint64_t* d_gather = nullptr; size_t gather_bytes = 0;
+  hipStream_t root_stream = nullptr;    // stream of the host-pointer calls / VC_STREAM_OWN
+  hipEvent_t ev_q = nullptr;            // "the batch's queries are ready" on the caller's stream
+  void* d_hq = nullptr;         size_t hq_bytes = 0;      // host-pointer API: staged queries, merged rows, counts, statistics
   uint64_t* d_out = nullptr;    size_t out_bytes = 0;
   uint32_t* d_ocnt = nullptr;   size_t ocnt_bytes = 0;
+  vc_query_stats* d_ostats = nullptr; size_t ostats_bytes = 0;
   RcclApi rccl;
   std::vector<ncclComm_t> comms;
   uint32_t exchange = VC_EXCHANGE_PEER_COPY;   // what is in use
@@ -136,29 +145,33 @@ static uint32_t shard_of(const vc_sharded* h, uint64_t pos) {   // pos relative 
   return g;
 }
 
+static uint64_t shard_size(const vc_sharded* h, uint32_t g) {   // records shard g holds (ingest fills the id ranges in order)
+  return h->n <= h->lo[g] ? 0 : std::min(h->n, h->hi[g]) - h->lo[g];
+}
+
 extern "C" {
 
 const char* vc_sharded_last_error(const vc_sharded* h) { return h ? h->err.c_str() : g_sharded_create_err.c_str(); }
 
 int vc_sharded_destroy(vc_sharded* h) {
   if (!h) return VC_OK;
-  for (uint32_t g = 0; g < h->buf.size(); ++g) {
-    (void)hipSetDevice(h->dev[g]);
-    if (h->buf[g].stream) (void)hipStreamSynchronize(h->buf[g].stream);
+  for (Lane& l : h->lanes) {
+    (void)hipSetDevice(l.dev);
+    (void)hipDeviceSynchronize();
   }
   if (!h->comms.empty() && h->rccl.CommDestroy)
     for (ncclComm_t c : h->comms)
       if (c) (void)h->rccl.CommDestroy(c);
-  for (uint32_t g = 0; g < h->buf.size(); ++g) {
-    (void)hipSetDevice(h->dev[g]);
-    ShardBuf& b = h->buf[g];
-    (void)hipFree(b.q); (void)hipFree(b.top); (void)hipFree(b.cnt); (void)hipFree(b.recv);
-    if (b.done) (void)hipEventDestroy(b.done);
-    if (b.stream) (void)hipStreamDestroy(b.stream);
+  for (Lane& l : h->lanes) {
+    (void)hipSetDevice(l.dev);
+    (void)hipFree(l.q); (void)hipFree(l.gath);
+    if (l.done) (void)hipEventDestroy(l.done);
+    if (l.stream) (void)hipStreamDestroy(l.stream);
   }
   for (vc_engine* e : h->eng) vc_destroy(e);
   (void)hipSetDevice(h->root);
-  (void)hipFree(h->d_gather); (void)hipFree(h->d_out); (void)hipFree(h->d_ocnt);
+  (void)hipFree(h->d_hq); (void)hipFree(h->d_out); (void)hipFree(h->d_ocnt); (void)hipFree(h->d_ostats);
+  if (h->ev_q) (void)hipEventDestroy(h->ev_q);
   if (h->root_stream) (void)hipStreamDestroy(h->root_stream);
   delete h;
   return VC_OK;
@@ -185,7 +198,7 @@ int vc_sharded_create(const vc_sharded_config* cfg, vc_sharded** out) {
   h->dev.resize(h->G);
   h->lo.resize(h->G);
   h->hi.resize(h->G);
-  h->buf.resize(h->G);
+  h->lane_of.resize(h->G);
   int rc = VC_OK;
   for (uint32_t g = 0; g < h->G && rc == VC_OK; ++g) {
     h->dev[g] = cfg->n_devices ? cfg->device_ids[g % h->D] : (int)(g % h->D);
@@ -199,14 +212,25 @@ int vc_sharded_create(const vc_sharded_config* cfg, vc_sharded** out) {
     ec.flags |= VC_FLAG_LEAN_TIMING;
     rc = vc_create(&ec, &h->eng[g]);
     if (rc != VC_OK) { g_sharded_create_err = std::string("shard ") + std::to_string(g) + ": " + vc_last_error(nullptr); break; }
-    if (hipSetDevice(h->dev[g]) != hipSuccess || hipStreamCreateWithFlags(&h->buf[g].stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->buf[g].done, hipEventDisableTiming) != hipSuccess)
-      rc = sfail(nullptr, VC_ERR_HIP, "shard %u: stream / event creation failed", g);
+    uint32_t li = 0;
+    while (li < h->lanes.size() && h->lanes[li].dev != h->dev[g]) ++li;
+    if (li == h->lanes.size()) {
+      h->lanes.emplace_back();
+      Lane& l = h->lanes.back();
+      l.dev = h->dev[g];
+      if (hipSetDevice(l.dev) != hipSuccess || hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess)
+        rc = sfail(nullptr, VC_ERR_HIP, "device %d: stream / event creation failed", l.dev);
+    }
+    h->lanes[li].shards.push_back(g);
+    h->lane_of[g] = li;
   }
   if (rc == VC_OK) {
     h->root = h->dev[0];
-    if (hipSetDevice(h->root) != hipSuccess || hipStreamCreateWithFlags(&h->root_stream, hipStreamNonBlocking) != hipSuccess)
-      rc = sfail(nullptr, VC_ERR_HIP, "root stream creation failed");
+    h->root_lane = h->lane_of[0];
+    if (hipSetDevice(h->root) != hipSuccess || hipStreamCreateWithFlags(&h->root_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming) != hipSuccess)
+      rc = sfail(nullptr, VC_ERR_HIP, "root stream / event creation failed");
   }
   // peer access root <- every other device (hipMemcpyPeerAsync works without it through a staged copy; with it the
   // copy is one xGMI transfer)
@@ -304,6 +328,7 @@ int vc_sharded_add_synthetic(vc_sharded* h, uint64_t n, uint64_t seed, uint32_t 
 int vc_sharded_build_index(vc_sharded* h) {
   if (!h) return VC_ERR_INVALID;
   for (uint32_t g = 0; g < h->G; ++g) {
+    if (shard_size(h, g) == 0) continue;   // a store filled below its capacity leaves the trailing shards empty: nothing to index
     int rc = vc_build_index(h->eng[g]);
     if (rc) return sfail(h, rc, "shard %u: %s", g, vc_last_error(h->eng[g]));
   }
@@ -321,6 +346,7 @@ int vc_sharded_get_bucket(vc_sharded* h, uint32_t table, uint32_t index, uint32_
   if (!h || !n) return VC_ERR_INVALID;
   uint32_t total = 0;
   for (uint32_t g = 0; g < h->G; ++g) {
+    if (shard_size(h, g) == 0) continue;
     uint32_t got = 0;
     const uint32_t room = total < cap ? cap - total : 0;
     int rc = vc_get_bucket(h->eng[g], table, index, ids ? ids + std::min(total, cap) : nullptr,
@@ -332,40 +358,148 @@ int vc_sharded_get_bucket(vc_sharded* h, uint32_t table, uint32_t index, uint32_
   return total ? VC_OK : VC_NOT_FOUND;
 }
 
-// one exchange: the shards' [nq][k] rows -> gathered [G][nq][k] on the root device, ordered on h->root_stream
-static int exchange_rows(vc_sharded* h, uint32_t nq, uint32_t k, const uint64_t** d_lists) {
-  const size_t rows = (size_t)nq * k;
-  if (h->exchange == VC_EXCHANGE_RCCL) {
-    for (uint32_t g = 0; g < h->G; ++g) {
-      VS_HIP(h, hipSetDevice(h->dev[g]));
-      int rc = sgrow(h, &h->buf[g].recv, &h->buf[g].recv_bytes, rows * 8 * h->G);
-      if (rc) return rc;
+// ---- a batch -------------------------------------------------------------------------------------------------
+// Slot of shard g in a gather buffer: [nq][k] rows | [nq] counts (padded to 8 bytes) | [nq] vc_query_stats (when wanted).
+// Rows, counts and statistics travel together: ONE peer copy per remote shard, or ONE all-gather.
+struct SlotLayout {
+  size_t rows, cnt_off, stats_off, words;
+  SlotLayout(uint32_t nq, uint32_t k, bool stats) {
+    rows = (size_t)nq * k;
+    cnt_off = rows;
+    stats_off = rows + ((size_t)nq + 1) / 2;
+    words = stats_off + (stats ? (size_t)nq * (sizeof(vc_query_stats) / 8) : 0);
+  }
+};
+static_assert(sizeof(vc_query_stats) == 40, "slot layout assumes 5 words per vc_query_stats");
+
+// SearchWorker::get_stat over the shards: every shard stops by its own rule -- the widest radius, the summed work
+__global__ void vc_sharded_stats_kernel(const uint64_t* __restrict__ base, uint64_t slot_words, uint64_t stats_off, uint32_t G, uint32_t nq,
+                                        const uint32_t* __restrict__ merged_cnt, vc_query_stats* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  vc_query_stats s{};
+  for (uint32_t g = 0; g < G; ++g) {
+    const vc_query_stats t = ((const vc_query_stats*)(base + (uint64_t)g * slot_words + stats_off))[i];
+    s.radius = max(s.radius, t.radius);
+    s.n_sub_reads += t.n_sub_reads;
+    s.n_local_reads += t.n_local_reads;
+    s.n_candidates += t.n_candidates;
+  }
+  s.n_results = merged_cnt[i];
+  out[i] = s;
+}
+
+// Everything of a batch is enqueued, nothing is waited for (LINEAR; the MIH modes make the host wait inside each shard's
+// vc_search_knn_dev -- how many queries continue decides what is enqueued next -- which is why lanes of different devices
+// then run on host threads): queries, rows, counts and statistics live in HBM on the root device, valid in `S` order.
+static int sharded_search_dev(vc_sharded* h, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode, uint64_t* d_out,
+                              uint32_t* d_counts, vc_query_stats* d_stats, hipStream_t S) {
+  const SlotLayout L(nq, k, d_stats != nullptr);
+  const size_t qbytes = (size_t)nq * h->nbytes;
+  int rc;
+  for (uint32_t li = 0; li < h->lanes.size(); ++li) {
+    Lane& l = h->lanes[li];
+    const bool everything = li == h->root_lane || h->exchange == VC_EXCHANGE_RCCL;   // gathered results of all shards land here
+    VS_HIP(h, hipSetDevice(l.dev));
+    if ((rc = sgrow(h, &l.gath, &l.gath_bytes, L.words * 8 * (everything ? h->G : l.shards.back() + 1)))) return rc;
+    if (li != h->root_lane && (rc = sgrow(h, (uint8_t**)&l.q, &l.q_bytes, qbytes))) return rc;
+  }
+  Lane& R = h->lanes[h->root_lane];
+  if (!d_counts) {
+    VS_HIP(h, hipSetDevice(h->root));
+    if ((rc = sgrow(h, &h->d_ocnt, &h->ocnt_bytes, (size_t)nq * 4))) return rc;
+    d_counts = h->d_ocnt;
+  }
+  // ---- the queries reach every device once: an event on the caller's stream, a peer copy per remote lane
+  if (h->lanes.size() > 1) {
+    VS_HIP(h, hipSetDevice(h->root));
+    VS_HIP(h, hipEventRecord(h->ev_q, S));
+    for (uint32_t li = 0; li < h->lanes.size(); ++li) {
+      if (li == h->root_lane) continue;
+      Lane& l = h->lanes[li];
+      VS_HIP(h, hipSetDevice(l.dev));
+      VS_HIP(h, hipStreamWaitEvent(l.stream, h->ev_q, 0));   // also orders the lane behind the previous batch's copies out of its slots
+      VS_HIP(h, hipMemcpyPeerAsync(l.q, l.dev, d_queries, h->root, qbytes, l.stream));
     }
+  }
+  // ---- every shard answers the batch for its id range, the shards of a device one after the other
+  std::vector<int> lane_rc(h->lanes.size(), VC_OK);
+  std::vector<std::string> lane_err(h->lanes.size());
+  auto run_lane = [&](uint32_t li) {
+    Lane& l = h->lanes[li];
+    const bool is_root = li == h->root_lane;
+    hipStream_t ls = is_root ? S : l.stream;
+    const void* q = is_root ? d_queries : l.q;
+    auto hip = [&](hipError_t r, const char* what) {
+      if (r != hipSuccess && lane_rc[li] == VC_OK) { lane_rc[li] = VC_ERR_HIP; lane_err[li] = std::string(what) + ": " + hipGetErrorString(r); }
+      return r == hipSuccess;
+    };
+    if (!hip(hipSetDevice(l.dev), "hipSetDevice")) return;
+    for (uint32_t g : l.shards) {
+      uint64_t* slot = l.gath + (size_t)g * L.words;
+      if (shard_size(h, g) == 0) {
+        // an empty shard (a store filled below its capacity) contributes INF rows, zero counts, zero statistics; its engine
+        // is never asked -- an exact radius loop over nothing would walk every shell of every table (search_worker.cc:170)
+        if (!hip(hipMemsetAsync(slot, 0xFF, L.rows * 8, ls), "hipMemsetAsync") ||
+            !hip(hipMemsetAsync(slot + L.cnt_off, 0, (L.words - L.cnt_off) * 8, ls), "hipMemsetAsync")) return;
+        continue;
+      }
+      const int r = vc_search_knn_dev_stats(h->eng[g], q, nq, k, mode, slot, (uint32_t*)(slot + L.cnt_off),
+                                            d_stats ? (vc_query_stats*)(slot + L.stats_off) : nullptr, ls);
+      if (r != VC_OK) { lane_rc[li] = r; lane_err[li] = std::string("shard ") + std::to_string(g) + ": " + vc_last_error(h->eng[g]); return; }
+    }
+    if (!is_root) hip(hipEventRecord(l.done, ls), "hipEventRecord");
+  };
+  if (mode == VC_MODE_LINEAR || h->lanes.size() == 1) {
+    for (uint32_t li = 0; li < h->lanes.size(); ++li) run_lane(li);
+  } else {
+    std::vector<std::thread> th;
+    for (uint32_t li = 0; li < h->lanes.size(); ++li) th.emplace_back(run_lane, li);
+    for (auto& t : th) t.join();
+  }
+  for (uint32_t li = 0; li < h->lanes.size(); ++li)
+    if (lane_rc[li]) return sfail(h, lane_rc[li], "%s", lane_err[li].c_str());
+  // ---- ONE exchange (replaces gather_vectors, mpi_coordinator.cc:34-69): every shard's slot -> the root's gather buffer
+  if (h->exchange == VC_EXCHANGE_RCCL) {
     ncclResult_t nr = h->rccl.GroupStart();
-    for (uint32_t g = 0; g < h->G && nr == ncclSuccess; ++g)   // rank g = shard g = device dev[g]; on the shard's own stream
-      nr = h->rccl.AllGather(h->buf[g].top, h->buf[g].recv, rows, ncclUint64, h->comms[g], h->buf[g].stream);
+    for (uint32_t g = 0; g < h->G && nr == ncclSuccess; ++g) {   // rank g = shard g = its device's lane; in place: the send slot sits in the receive buffer
+      Lane& l = h->lanes[h->lane_of[g]];
+      nr = h->rccl.AllGather(l.gath + (size_t)g * L.words, l.gath, L.words, ncclUint64, h->comms[g], h->lane_of[g] == h->root_lane ? S : l.stream);
+    }
     const ncclResult_t ne = h->rccl.GroupEnd();
     if (nr == ncclSuccess) nr = ne;
     if (nr != ncclSuccess) return sfail(h, VC_ERR_HIP, "ncclAllGather: %s", h->rccl.GetErrorString(nr));
-    // the root merges from its own copy, behind its shard's stream
+  } else {
     VS_HIP(h, hipSetDevice(h->root));
-    VS_HIP(h, hipEventRecord(h->buf[0].done, h->buf[0].stream));
-    VS_HIP(h, hipStreamWaitEvent(h->root_stream, h->buf[0].done, 0));
-    *d_lists = h->buf[0].recv;
-    return VC_OK;
+    for (uint32_t li = 0; li < h->lanes.size(); ++li) {
+      if (li == h->root_lane) continue;      // the root's shards wrote their slots in place
+      Lane& l = h->lanes[li];
+      VS_HIP(h, hipStreamWaitEvent(S, l.done, 0));
+      for (uint32_t g : l.shards)
+        VS_HIP(h, hipMemcpyPeerAsync(R.gath + (size_t)g * L.words, h->root, l.gath + (size_t)g * L.words, l.dev, L.words * 8, S));
+    }
   }
+  // ---- merge (replaces the master's heap, search_worker.cc:179-199); a flagged shard row flags the merged row
   VS_HIP(h, hipSetDevice(h->root));
-  int rc = sgrow(h, &h->d_gather, &h->gather_bytes, rows * 8 * h->G);
-  if (rc) return rc;
-  for (uint32_t g = 0; g < h->G; ++g) {
-    VS_HIP(h, hipStreamWaitEvent(h->root_stream, h->buf[g].done, 0));
-    if (h->dev[g] == h->root)
-      VS_HIP(h, hipMemcpyAsync(h->d_gather + (size_t)g * rows, h->buf[g].top, rows * 8, hipMemcpyDeviceToDevice, h->root_stream));
-    else
-      VS_HIP(h, hipMemcpyPeerAsync(h->d_gather + (size_t)g * rows, h->root, h->buf[g].top, h->dev[g], rows * 8, h->root_stream));
+  VS_HIP(h, vc_launch_select_slots(R.gath, L.words, (uint32_t)L.cnt_off, h->G, nq, k, d_out, d_counts, S));
+  if (d_stats) {
+    hipLaunchKernelGGL(vc_sharded_stats_kernel, dim3((nq + 255) / 256), dim3(256), 0, S, (const uint64_t*)R.gath, (uint64_t)L.words,
+                       (uint64_t)L.stats_off, h->G, nq, (const uint32_t*)d_counts, d_stats);
+    VS_HIP(h, hipGetLastError());
   }
-  *d_lists = h->d_gather;
   return VC_OK;
+}
+
+int vc_sharded_root_device(const vc_sharded* h, int* device) {
+  if (!h || !device) return VC_ERR_INVALID;
+  *device = h->root;
+  return VC_OK;
+}
+
+int vc_sharded_search_knn_dev(vc_sharded* h, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode, uint64_t* d_out,
+                              uint32_t* d_counts, vc_query_stats* d_stats, void* stream) {
+  if (!h || !d_queries || !d_out || nq == 0 || k == 0 || k > VC_MAX_K || mode > VC_MODE_MIH_APPROX) return VC_ERR_INVALID;
+  return sharded_search_dev(h, d_queries, nq, k, mode, d_out, d_counts, d_stats, stream == VC_STREAM_OWN ? h->root_stream : (hipStream_t)stream);
 }
 
 int vc_sharded_search_knn(vc_sharded* h, const void* queries, uint32_t nq, uint32_t k, uint32_t mode, uint32_t order,
@@ -373,102 +507,55 @@ int vc_sharded_search_knn(vc_sharded* h, const void* queries, uint32_t nq, uint3
   if (!h || !queries || !out || nq == 0 || k == 0 || k > VC_MAX_K || mode > VC_MODE_MIH_APPROX || order > VC_ORDER_FARTHEST_FIRST)
     return VC_ERR_INVALID;
   const size_t qbytes = (size_t)nq * h->nbytes, rows = (size_t)nq * k;
-  std::vector<std::vector<vc_query_stats>> sstat;
   int rc;
-  // ---- every shard answers the batch for its id range
-  for (uint32_t g = 0; g < h->G; ++g) {
-    ShardBuf& b = h->buf[g];
-    VS_HIP(h, hipSetDevice(h->dev[g]));
-    if ((rc = sgrow(h, (uint8_t**)&b.q, &b.q_bytes, qbytes))) return rc;
-    if ((rc = sgrow(h, &b.top, &b.top_bytes, rows * 8))) return rc;
-    if ((rc = sgrow(h, &b.cnt, &b.cnt_bytes, (size_t)nq * 4))) return rc;
-  }
-  // host-API leg: MIH modes (every shard runs its queries to its LOCAL stop rule -- exact for the shard -- and the host
-  // API reports the statistics), and the fallback of a linear batch whose device-side ring-overflow recovery gave up.
-  // The calls synchronise, so the shards run on threads of their own; rows land in the shards' device buffers.
-  auto host_leg = [&](uint32_t leg_mode) -> int {
-    sstat.assign(h->G, std::vector<vc_query_stats>(nq));
-    std::vector<int> rcs(h->G, VC_OK);
-    std::vector<std::vector<uint64_t>> rows_h(h->G, std::vector<uint64_t>(rows));
-    auto work = [&](uint32_t g) {
-      std::vector<uint32_t> c(nq);
-      rcs[g] = vc_search_knn(h->eng[g], queries, nq, k, leg_mode, VC_ORDER_ASCENDING, rows_h[g].data(), c.data(), sstat[g].data());
-      if (rcs[g] == VC_OK)
-        for (uint32_t i = 0; i < nq; ++i)
-          for (uint32_t j = c[i]; j < k; ++j) rows_h[g][(size_t)i * k + j] = VC_PACK_INF;
-    };
-    if (h->G == 1) {
-      work(0);
-    } else {
-      std::vector<std::thread> th;
-      for (uint32_t g = 0; g < h->G; ++g) th.emplace_back(work, g);
-      for (auto& t : th) t.join();
-    }
-    for (uint32_t g = 0; g < h->G; ++g)
-      if (rcs[g]) return sfail(h, rcs[g], "shard %u: %s", g, vc_last_error(h->eng[g]));
-    for (uint32_t g = 0; g < h->G; ++g) {
-      ShardBuf& b = h->buf[g];
-      VS_HIP(h, hipSetDevice(h->dev[g]));
-      VS_HIP(h, hipMemcpyAsync(b.top, rows_h[g].data(), rows * 8, hipMemcpyHostToDevice, b.stream));
-      VS_HIP(h, hipStreamSynchronize(b.stream));   // rows_h goes out of scope
-      VS_HIP(h, hipEventRecord(b.done, b.stream));
-    }
-    return VC_OK;
-  };
-  if (mode == VC_MODE_LINEAR) {
-    // asynchronous on every shard's own stream: the devices scan concurrently
-    for (uint32_t g = 0; g < h->G; ++g) {
-      ShardBuf& b = h->buf[g];
-      VS_HIP(h, hipSetDevice(h->dev[g]));
-      VS_HIP(h, hipMemcpyAsync(b.q, queries, qbytes, hipMemcpyHostToDevice, b.stream));
-      rc = vc_search_knn_dev(h->eng[g], b.q, nq, k, mode, b.top, b.cnt, b.stream);
-      if (rc) return sfail(h, rc, "shard %u: %s", g, vc_last_error(h->eng[g]));
-      VS_HIP(h, hipEventRecord(b.done, b.stream));
-    }
-    // a shard whose device-side recovery gave up flags its rows with count UINT32_MAX (vc_search_knn_dev): upper bounds
-    // only -- the batch is then answered through the host API, which recovers on the host (never seen outside tests)
-    bool gave_up = false;
-    std::vector<uint32_t> c(nq);
-    for (uint32_t g = 0; g < h->G; ++g) {
-      VS_HIP(h, hipSetDevice(h->dev[g]));
-      VS_HIP(h, hipMemcpyAsync(c.data(), h->buf[g].cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, h->buf[g].stream));
-      VS_HIP(h, hipStreamSynchronize(h->buf[g].stream));
-      for (uint32_t i = 0; i < nq; ++i) gave_up = gave_up || c[i] == 0xFFFFFFFFu;
-    }
-    if (gave_up && (rc = host_leg(VC_MODE_LINEAR))) return rc;
-  } else if ((rc = host_leg(mode))) {
-    return rc;
-  }
-  // ---- one exchange + merge (replaces gather_vectors + the master's heap)
-  const uint64_t* d_lists = nullptr;
-  if ((rc = exchange_rows(h, nq, k, &d_lists))) return rc;
+  hipStream_t S = h->root_stream;
   VS_HIP(h, hipSetDevice(h->root));
+  if ((rc = sgrow(h, (uint8_t**)&h->d_hq, &h->hq_bytes, qbytes))) return rc;
   if ((rc = sgrow(h, &h->d_out, &h->out_bytes, rows * 8))) return rc;
   if ((rc = sgrow(h, &h->d_ocnt, &h->ocnt_bytes, (size_t)nq * 4))) return rc;
-  if ((rc = vc_merge_topk_dev(d_lists, h->G, nq, k, h->d_out, h->d_ocnt, h->root_stream))) return sfail(h, rc, "merge: %s", vc_last_error(nullptr));
+  if (stats && (rc = sgrow(h, &h->d_ostats, &h->ostats_bytes, (size_t)nq * sizeof(vc_query_stats)))) return rc;
+  VS_HIP(h, hipMemcpyAsync(h->d_hq, queries, qbytes, hipMemcpyHostToDevice, S));
+  if ((rc = sharded_search_dev(h, h->d_hq, nq, k, mode, h->d_out, h->d_ocnt, stats ? h->d_ostats : nullptr, S))) return rc;
   std::vector<uint32_t> cnt(nq);
-  VS_HIP(h, hipMemcpyAsync(out, h->d_out, rows * 8, hipMemcpyDeviceToHost, h->root_stream));
-  VS_HIP(h, hipMemcpyAsync(cnt.data(), h->d_ocnt, (size_t)nq * 4, hipMemcpyDeviceToHost, h->root_stream));
-  VS_HIP(h, hipStreamSynchronize(h->root_stream));
+  VS_HIP(h, hipSetDevice(h->root));
+  VS_HIP(h, hipMemcpyAsync(out, h->d_out, rows * 8, hipMemcpyDeviceToHost, S));
+  VS_HIP(h, hipMemcpyAsync(cnt.data(), h->d_ocnt, (size_t)nq * 4, hipMemcpyDeviceToHost, S));
+  if (stats) VS_HIP(h, hipMemcpyAsync(stats, h->d_ostats, (size_t)nq * sizeof(vc_query_stats), hipMemcpyDeviceToHost, S));
+  VS_HIP(h, hipStreamSynchronize(S));
+  bool gave_up = false;
+  for (uint32_t i = 0; i < nq; ++i) gave_up = gave_up || cnt[i] == 0xFFFFFFFFu;
+  if (gave_up && mode == VC_MODE_LINEAR) {
+    // A shard's device-side ring-overflow recovery gave up (its grid never met; never seen outside tests): the batch is
+    // answered again through the shards' host API, whose host-driven recovery always ends, one shard after the other;
+    // the rows go back into the root's slots and are merged by the same kernel.
+    const SlotLayout L(nq, k, false);
+    Lane& R = h->lanes[h->root_lane];
+    VS_HIP(h, hipSetDevice(h->root));
+    if ((rc = sgrow(h, &R.gath, &R.gath_bytes, L.words * 8 * h->G))) return rc;
+    std::vector<uint64_t> slot(L.words);
+    for (uint32_t g = 0; g < h->G; ++g) {
+      uint32_t* c = (uint32_t*)(slot.data() + L.cnt_off);
+      std::fill(slot.begin(), slot.begin() + L.rows, VC_PACK_INF);
+      std::fill(slot.begin() + L.rows, slot.end(), 0ull);
+      if (shard_size(h, g)) {
+        rc = vc_search_knn(h->eng[g], queries, nq, k, VC_MODE_LINEAR, VC_ORDER_ASCENDING, slot.data(), c, nullptr);
+        if (rc) return sfail(h, rc, "shard %u: %s", g, vc_last_error(h->eng[g]));
+        for (uint32_t i = 0; i < nq; ++i)
+          for (uint32_t j = c[i]; j < k; ++j) slot[(size_t)i * k + j] = VC_PACK_INF;
+      }
+      VS_HIP(h, hipSetDevice(h->root));
+      VS_HIP(h, hipMemcpyAsync(R.gath + (size_t)g * L.words, slot.data(), L.words * 8, hipMemcpyHostToDevice, S));
+      VS_HIP(h, hipStreamSynchronize(S));   // `slot` is reused by the next shard
+    }
+    VS_HIP(h, vc_launch_select_slots(R.gath, L.words, (uint32_t)L.cnt_off, h->G, nq, k, h->d_out, h->d_ocnt, S));
+    VS_HIP(h, hipMemcpyAsync(out, h->d_out, rows * 8, hipMemcpyDeviceToHost, S));
+    VS_HIP(h, hipMemcpyAsync(cnt.data(), h->d_ocnt, (size_t)nq * 4, hipMemcpyDeviceToHost, S));
+    VS_HIP(h, hipStreamSynchronize(S));
+  }
   for (uint32_t i = 0; i < nq; ++i) {
     if (order == VC_ORDER_FARTHEST_FIRST) std::reverse(out + (size_t)i * k, out + (size_t)i * k + cnt[i]);
     if (counts) counts[i] = cnt[i];
-    if (stats) {
-      vc_query_stats s{};
-      if (mode == VC_MODE_LINEAR) {
-        s.n_candidates = h->n;
-      } else {
-        for (uint32_t g = 0; g < h->G; ++g) {   // every shard stops by its own rule: the widest radius, the summed work
-          const vc_query_stats& t = sstat[g][i];
-          s.radius = std::max(s.radius, t.radius);
-          s.n_sub_reads += t.n_sub_reads;
-          s.n_local_reads += t.n_local_reads;
-          s.n_candidates += t.n_candidates;
-        }
-      }
-      s.n_results = cnt[i];
-      stats[i] = s;
-    }
+    if (stats) stats[i].n_results = cnt[i];
   }
   return VC_OK;
 }

@@ -30,7 +30,7 @@ EXPORTS = [
     "vc_search_radius_dev", "vc_read_bitmap_file", "vc_save_index", "vc_load_index",
     "vc_sharded_create", "vc_sharded_destroy", "vc_sharded_last_error", "vc_sharded_exchange", "vc_sharded_add_codes",
     "vc_sharded_add_synthetic", "vc_sharded_size", "vc_sharded_build_index", "vc_sharded_get_code", "vc_sharded_get_bucket",
-    "vc_sharded_search_knn", "vc_sharded_shard",
+    "vc_sharded_search_knn", "vc_sharded_shard", "vc_sharded_search_knn_dev", "vc_sharded_root_device", "vc_search_knn_dev_stats",
 ]
 MAX_SHARDS = 16
 EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL = 0, 1, 2
@@ -110,6 +110,7 @@ def load_library():
     L.vc_bitmap_read.argtypes = [vp, u32, u64, u64, vp]
     L.vc_search_knn.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]
     L.vc_search_knn_dev.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp]
+    L.vc_search_knn_dev_stats.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp, vp]
     L.vc_search_radius.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp]
     L.vc_search_radius_dev.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp, vp]
     L.vc_merge_topk_dev.argtypes = [vp, u32, u32, u32, vp, vp, vp]
@@ -135,6 +136,8 @@ def load_library():
     L.vc_sharded_get_bucket.argtypes = [vp, u32, u32, vp, vp, u32, C.POINTER(u32)]
     L.vc_sharded_search_knn.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp]
     L.vc_sharded_shard.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.vc_sharded_search_knn_dev.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp, vp]
+    L.vc_sharded_root_device.argtypes = [vp, C.POINTER(C.c_int)]
     for name in EXPORTS:
         if getattr(L, name).restype is not C.c_char_p:
             getattr(L, name).restype = C.c_int
@@ -174,9 +177,19 @@ class Engine:
             raise VcError(rc, self._L.vc_last_error(self._h).decode() or self._L.vc_strerror(rc).decode())
         return rc
 
+    @classmethod
+    def borrowed(cls, handle, bits, n_tables=0, id_base=0):
+        """a view of an engine somebody else owns (a shard of a ShardedEngine): every call works, close() does not destroy"""
+        e = cls.__new__(cls)
+        e._L = load_library()
+        e.bits, e.nbytes, e.n_tables, e.id_base = bits, bits // 8, n_tables, id_base
+        e._h, e._borrowed = handle, True
+        return e
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.vc_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._L.vc_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -290,6 +303,10 @@ class Engine:
         PyTorch's default stream, so the call is ordered with torch work either way."""
         self._check(self._L.vc_search_knn_dev(self._h, d_queries, nq, k, mode, d_out, d_counts, stream))
 
+    def search_knn_dev_stats(self, d_queries, nq, k, d_out, d_counts, d_stats, mode=MODE_LINEAR, stream=None):
+        """vc_search_knn_dev_stats: the same + nq VcQueryStats records written to device memory (d_stats, raw address) in stream order"""
+        self._check(self._L.vc_search_knn_dev_stats(self._h, d_queries, nq, k, mode, d_out, d_counts, d_stats, stream))
+
     def search_radius(self, queries, radius, mode=MODE_LINEAR, cap_per_query=4096):
         q = self._queries(queries)
         nq = q.shape[0]
@@ -337,14 +354,14 @@ class ShardedEngine:
     (replaces mpirun ranks + MPI gathers + the master heap, search_worker.cc:99-101,177-207)."""
 
     def __init__(self, bits, capacity, n_shards, n_tables=0, devices=None, exchange=EXCHANGE_AUTO, flags=0, id_base=0,
-                 cand_cap=0, query_tile=0):
+                 cand_cap=0, query_tile=0, timing_sample=0):
         self._L = load_library()
-        self.bits, self.nbytes, self.n_shards = bits, bits // 8, n_shards
+        self.bits, self.nbytes, self.n_shards, self.n_tables = bits, bits // 8, n_shards, n_tables
         cfg = VcShardedConfig(abi_version=VC_ABI_VERSION, n_shards=n_shards, n_devices=len(devices or []), exchange=exchange)
         for i, d in enumerate(devices or []):
             cfg.device_ids[i] = d
         cfg.engine = VcConfig(abi_version=VC_ABI_VERSION, bits=bits, n_tables=n_tables, flags=flags, capacity=capacity,
-                              id_base=id_base, device=-1, cand_cap=cand_cap, query_tile=query_tile)
+                              id_base=id_base, device=-1, cand_cap=cand_cap, query_tile=query_tile, timing_sample=timing_sample)
         h = C.c_void_p()
         rc = self._L.vc_sharded_create(C.byref(cfg), C.byref(h))
         if rc != VC_OK:
@@ -410,6 +427,22 @@ class ShardedEngine:
         first, cnt = C.c_uint64(), C.c_uint64()
         self._check(self._L.vc_sharded_shard(self._h, g, None, C.byref(first), C.byref(cnt)))
         return first.value, cnt.value
+
+    def shard(self, g):
+        """shard g's engine, borrowed (timing, bucket views, files); valid while this store lives"""
+        e, first = C.c_void_p(), C.c_uint64()
+        self._check(self._L.vc_sharded_shard(self._h, g, C.byref(e), C.byref(first), None))
+        return Engine.borrowed(e, self.bits, self.n_tables, first.value)
+
+    @property
+    def root_device(self):
+        d = C.c_int()
+        self._check(self._L.vc_sharded_root_device(self._h, C.byref(d)))
+        return d.value
+
+    def search_knn_dev(self, d_queries, nq, k, d_out, d_counts=None, d_stats=None, mode=MODE_LINEAR, stream=None):
+        """vc_sharded_search_knn_dev: raw device addresses on the root device; results valid in `stream` order"""
+        self._check(self._L.vc_sharded_search_knn_dev(self._h, d_queries, nq, k, mode, d_out, d_counts, d_stats, stream))
 
     def search_knn(self, queries, k, mode=MODE_LINEAR, order=ORDER_ASCENDING, with_stats=False):
         q = np.ascontiguousarray(queries, dtype=np.uint8)
