@@ -235,3 +235,37 @@ def test_cache_resident_prefix_does_not_change_results(vc, oracle, monkeypatch, 
                 got, cnt = e.search_knn(q, k)
                 for i in range(len(q)):
                     assert np.array_equal(got[i, : cnt[i]], exp[i]), (mb, i)
+
+
+@pytest.mark.parametrize("n_lists,nq,k", [(1, 3, 7), (2, 8, 100), (8, 8, 100), (8, 4096, 100), (16, 5, 1), (5, 9, 333), (16, 3, 1000), (3, 2, 8192)])
+def test_merge_of_sorted_lists_equals_numpy(vc, n_lists, nq, k):
+    """vc_merge_topk_dev (gather_vectors' consumer + the master heap, mpi_coordinator.cc:34-69, search_worker.cc:179-199):
+    ascending INF-padded lists -> the k smallest, ascending, INF-padded, valid counts -- on the LDS merge kernel (up to
+    6144 entries per query) and on the general select kernel behind it; partly filled and empty lists, a value that occurs
+    in several lists (overlapping shards are not the engine's case, but the entry point takes any lists)"""
+    import torch
+    rng = np.random.default_rng(n_lists * 1000 + k)
+    INF = np.uint64(0xFFFFFFFFFFFFFFFF)
+    lists = np.full((n_lists, nq, k), INF, dtype=np.uint64)
+    for g in range(n_lists):
+        for q in range(nq if nq <= 64 else 64):
+            fill = int(rng.integers(0, k + 1)) if (g + q) % 3 else k
+            vals = (rng.integers(0, 128, size=fill).astype(np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 32, size=fill).astype(np.uint64)
+            vals = np.unique(vals)
+            lists[g, q, : len(vals)] = vals
+    if nq > 64:
+        lists[:, 64:] = lists[:, :1]                               # the same query many times: every list equal = duplicates across lists
+    if n_lists > 1 and k > 1:
+        lists[1, 0, 0] = lists[0, 0, 0]                             # a duplicate across two lists, at the front
+        lists[1, 0] = np.sort(lists[1, 0])
+    d = torch.from_numpy(lists.view(np.int64)).cuda()
+    out = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    vc.merge_topk_dev(d.data_ptr(), n_lists, nq, k, out.data_ptr(), cnt.data_ptr())
+    torch.cuda.synchronize()
+    got, c = out.cpu().numpy().view(np.uint64), cnt.cpu().numpy()
+    for q in range(nq):
+        allv = np.sort(lists[:, q].reshape(-1))
+        exp = allv[:k]
+        assert np.array_equal(got[q], exp), (q, n_lists, k)
+        assert c[q] == int((exp != INF).sum())
