@@ -48,11 +48,11 @@ def test_shipped_query_kernels_of_the_configs_shapes_have_no_scratch(vc):
     if not os.path.exists(obj):
         vb.build(force=True)
     res = {k: v for k, v in vb.kernel_resources(obj).items() if "mih_query_kernel" in k}
-    assert len(res) == 8                              # W = 1, 2, 4, 8 x the two granule widths
+    assert len(res) == 12                             # W = 1, 2, 4, 8 x {radius granules, k-NN granules, k-NN over directory lines}
     narrow = {k: v for k, v in res.items() if "ILi1E" in k or "ILi2E" in k}
-    assert len(narrow) == 4
+    assert len(narrow) == 6
     for k, v in narrow.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
-        assert v["vgpr_count"] <= 128 and v["sgpr_spill_count"] <= 80, (k, v)
+        assert v["vgpr_count"] <= 128 and v["sgpr_spill_count"] <= 64, (k, v)   # (more than 64 need a second VGPR for their lanes)
     stream = {k: v for k, v in vb.kernel_resources(obj).items() if "mih_bucket_stream_kernel" in k}
     assert stream and all(v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 for v in stream.values())

@@ -36,26 +36,45 @@ __host__ __device__ inline uint64_t vc_pack(uint32_t dist, uint32_t id) { return
 // ---- wave64 helpers --------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t vc_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// exclusive prefix sum over the 64 lanes of a wave (cold paths only: shuffle ladder)
+// Wave64 scan / reduction on the DPP cross-lane path (row_shr inside the rows of 16, row_bcast:15 / :31 across them -- gfx9
+// encodings): no LDS traffic and, unlike a __shfl ladder (ds_bpermute), no per-lane index registers -- hipcc hoisted those
+// twelve index computations to kernel entry and kept them alive through kernels that sit at their VGPR limit (r04:
+// mih_query_kernel spilled `lane` itself next to them).
+#define VC_DPP_ROW_SHR(n) (0x110 + (n))
+#define VC_DPP_ROW_BCAST15 0x142
+#define VC_DPP_ROW_BCAST31 0x143
+__device__ __forceinline__ uint32_t vc_wave_incl_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, VC_DPP_ROW_SHR(1), 0xf, 0xf, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, VC_DPP_ROW_SHR(2), 0xf, 0xf, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, VC_DPP_ROW_SHR(4), 0xf, 0xf, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, VC_DPP_ROW_SHR(8), 0xf, 0xf, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, VC_DPP_ROW_BCAST15, 0xa, 0xf, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, VC_DPP_ROW_BCAST31, 0xc, 0xf, false);
+  return x;
+}
+
+// exclusive prefix sum over the 64 lanes of a wave; total = the wave's sum (wave-uniform)
 __device__ __forceinline__ uint32_t vc_wave_excl_scan(uint32_t v, uint32_t& total) {
-  const uint32_t lane = vc_lane();
-  uint32_t x = v;
-#pragma unroll
-  for (int off = 1; off < VC_WAVE; off <<= 1) {
-    uint32_t y = __shfl_up(x, off, VC_WAVE);
-    if (lane >= (uint32_t)off) x += y;
-  }
-  total = __shfl(x, VC_WAVE - 1, VC_WAVE);
+  const uint32_t x = vc_wave_incl_scan(v);
+  total = (uint32_t)__builtin_amdgcn_readlane((int)x, VC_WAVE - 1);
   return x - v;
 }
 
+// minimum over the 64 lanes of a wave (wave-uniform result)
 __device__ __forceinline__ uint32_t vc_wave_min(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    uint32_t y = __shfl_xor(v, off, VC_WAVE);
-    v = y < v ? y : v;
+#define VC_MIN_STEP(ctrl, row_mask)                                                                                                  \
+  {                                                                                                                                  \
+    const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, row_mask, 0xf, false); /* no source: keeps v */ \
+    v = y < v ? y : v;                                                                                                               \
   }
-  return v;
+  VC_MIN_STEP(VC_DPP_ROW_SHR(1), 0xf)
+  VC_MIN_STEP(VC_DPP_ROW_SHR(2), 0xf)
+  VC_MIN_STEP(VC_DPP_ROW_SHR(4), 0xf)
+  VC_MIN_STEP(VC_DPP_ROW_SHR(8), 0xf)
+  VC_MIN_STEP(VC_DPP_ROW_BCAST15, 0xa)
+  VC_MIN_STEP(VC_DPP_ROW_BCAST31, 0xc)
+#undef VC_MIN_STEP
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, VC_WAVE - 1);
 }
 
 // in-place bitonic sort of a[0..P) (P a power of two) in LDS or global memory by one block of `nthreads` threads

@@ -56,9 +56,25 @@ struct VcTableView {
   // Optional, 32-bit substrings of 64- / 128-bit codes: {id, 0, code} of the pos-th entry in ONE 16- / 32-byte record.
   // Their buckets hold one entry, and ids[pos] -> cols[id] are two (three) dependent sectors per hit where this is one.
   const uint4* bent;
+  // Optional, 32-bit substrings: DIRECTORY LINES -- one 64-byte line (= one memory sector) per 128 keys that holds the
+  // occupancy bits of those keys AND what a hit needs next, so that a probe's granule read and its bucket look-up touch
+  // ONE sector (the second access is an L2 hit) where bitmap -> blockoff -> offsets[] were up to three dependent sectors:
+  //   words 0..3   occupancy bits of keys [128 L, 128 L + 128)   (== bitmap words 4 L .. 4 L + 3)
+  //   word  4      entry position of the line's first bucket     (== offsets[rank of the line's first set bit])
+  //   word  5      set bits before the line (rank of its first set bit)
+  //   word  6      non-empty buckets in the line | mode << 8
+  //   word  7      entries in the line
+  //   words 8..15  mode 1 (<= 16 buckets, < 65 536 entries): 16-bit cumulative END offsets of the buckets, rank order;
+  //                mode 2 (every bucket <= 4 entries): 2-bit (length - 1) per bucket, rank order;
+  //                mode 0: neither fits -- the hit falls back to offsets[rank] (one more dependent sector)
+  // 2 GB per table; derived at build / load like blockoff, not part of the index file.
+  const uint4* lines;
   uint32_t n_unique;
   uint32_t pad;
 };
+#define MIH_LINE_MODE_OFFSETS 0u
+#define MIH_LINE_MODE_CUM16 1u
+#define MIH_LINE_MODE_LEN2 2u
 
 __constant__ uint32_t c_binom[33][33];  // C(n, k), n,k <= 32 (max C(32,16) = 601,080,390 fits uint32)
 
@@ -150,6 +166,78 @@ __global__ void __launch_bounds__(256) mih_blockoff_kernel(const uint32_t* __res
     const uint32_t rk = b < nblocks ? blockrank[b] : n_unique;
     blockoff[b] = make_uint2(offsets[rk], rk);
   }
+}
+
+// directory lines (VcTableView::lines): one thread per 128-key line
+__global__ void __launch_bounds__(256) mih_lines_kernel(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ blockrank,
+                                                        const uint32_t* __restrict__ offsets, uint32_t nlines, uint4* __restrict__ lines) {
+  for (uint32_t L = blockIdx.x * blockDim.x + threadIdx.x; L < nlines; L += gridDim.x * blockDim.x) {
+    const uint4 occ = reinterpret_cast<const uint4*>(bitmap)[L];
+    uint32_t rank = blockrank[L >> 1];
+    if (L & 1u) {
+      const uint4 lo = reinterpret_cast<const uint4*>(bitmap)[L - 1];
+      rank += __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w);
+    }
+    const uint32_t nb = __popc(occ.x) + __popc(occ.y) + __popc(occ.z) + __popc(occ.w);
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t mode = MIH_LINE_MODE_OFFSETS, pos0 = 0, total = 0;
+    if (nb) {
+      pos0 = offsets[rank];
+      total = offsets[rank + nb] - pos0;
+      if (nb <= 16 && total < 65536u) {
+        mode = MIH_LINE_MODE_CUM16;
+        for (uint32_t i = 0; i < nb; ++i) w[i >> 1] |= (offsets[rank + i + 1] - pos0) << ((i & 1u) * 16u);
+      } else if (total <= 4u * nb) {     // (necessary for "every bucket <= 4 entries"; checked bucket by bucket below)
+        mode = MIH_LINE_MODE_LEN2;
+        uint32_t prev = pos0;
+        for (uint32_t i = 0; i < nb; ++i) {
+          const uint32_t e = offsets[rank + i + 1], len = e - prev;
+          prev = e;
+          if (len > 4u) mode = MIH_LINE_MODE_OFFSETS;
+          w[i >> 4] |= ((len - 1u) & 3u) << ((i & 15u) * 2u);
+        }
+      }
+    }
+    uint4* dst = lines + (uint64_t)L * 4;
+    dst[0] = occ;
+    dst[1] = make_uint4(pos0, rank, nb | (mode << 8), total);
+    dst[2] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[3] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+
+// bucket (entry position, length) of the key whose bit is x (0..127) in a directory line held in registers; false = mode 0
+__device__ __forceinline__ bool vc_line_lookup(const uint4& occ, const uint4& dir, const uint4& f0, const uint4& f1, uint32_t x,
+                                               uint32_t& pos, uint32_t& len, uint32_t& rk) {
+  const uint32_t wq = x >> 5, below_mask = (1u << (x & 31u)) - 1u;
+  const uint32_t r = (wq > 0 ? __popc(occ.x) : 0u) + (wq > 1 ? __popc(occ.y) : 0u) + (wq > 2 ? __popc(occ.z) : 0u) +
+                     __popc((wq == 0 ? occ.x : wq == 1 ? occ.y : wq == 2 ? occ.z : occ.w) & below_mask);
+  rk = dir.y + r;
+  const uint32_t mode = dir.z >> 8;
+  auto sel8 = [&](uint32_t i) {      // word i of f0 | f1 by masks (a select chain here was turned into a scratch array by hipcc)
+    auto pick = [&](uint32_t wv, uint32_t j) { return wv & (0u - (uint32_t)(i == j)); };
+    return pick(f0.x, 0) | pick(f0.y, 1) | pick(f0.z, 2) | pick(f0.w, 3) | pick(f1.x, 4) | pick(f1.y, 5) | pick(f1.z, 6) | pick(f1.w, 7);
+  };
+  if (mode == MIH_LINE_MODE_CUM16) {
+    const uint32_t end = (sel8(r >> 1) >> ((r & 1u) * 16u)) & 0xFFFFu;
+    const uint32_t beg = r ? (sel8((r - 1u) >> 1) >> (((r - 1u) & 1u) * 16u)) & 0xFFFFu : 0u;
+    pos = dir.x + beg;
+    len = end - beg;
+    return true;
+  }
+  if (mode == MIH_LINE_MODE_LEN2) {
+    uint32_t extra = 0;                 // sum of (length - 1) of the r buckets below: the low 2 r bits of the 256-bit field array
+    auto part = [&](uint32_t wv, int i) {
+      const int nbits = (int)(2u * r) - 32 * i;
+      const uint32_t mk = nbits >= 32 ? 0xFFFFFFFFu : (nbits <= 0 ? 0u : ((1u << nbits) - 1u));
+      extra += __popc(wv & 0x55555555u & mk) + 2u * __popc(wv & 0xAAAAAAAAu & mk);
+    };
+    part(f0.x, 0); part(f0.y, 1); part(f0.z, 2); part(f0.w, 3); part(f1.x, 4); part(f1.y, 5); part(f1.z, 6); part(f1.w, 7);
+    pos = dir.x + r + extra;
+    len = ((sel8(r >> 4) >> ((r & 15u) * 2u)) & 3u) + 1u;
+    return true;
+  }
+  return false;
 }
 
 // ImageBitmap::get_idx (bitmap.cc:22-26)
@@ -651,6 +739,12 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 #define MQ_TAG_SHIFT 62
 #define MQ_TAG_MASK (3ull << MQ_TAG_SHIFT)
 #define MQ_MAX_GROUP 3u
+#ifndef MQ_LAZY_BINOM
+#define MQ_LAZY_BINOM 1
+#endif
+#ifndef MQ_PERSISTENT
+#define MQ_PERSISTENT 0     // 1: a residency wave of blocks draws queries from a ticket (r04: +3 % against one block per query in the same
+#endif                      // binary, but the loop around the body costs ~20 spilled VGPRs at the 128-register limit: -8 % net) -- off
 static __host__ __device__ inline uint32_t mq_hist_bins(uint32_t W) { return (W * 64u + 1u + 7u) & ~7u; }
 
 struct QueryKernelParams {
@@ -672,6 +766,9 @@ struct QueryKernelParams {
   uint64_t* out;               // k-NN: [nq][k] rows
   uint32_t* out_cnt;
   unsigned long long* phase_dbg;  // dev (VC_MIH_PHASES): [8] phase times of mih_query_kernel, summed over the launch; [8..13] block lifetimes by stop shell (0..4, handed over), [16..21] their counts, [24] start of the first block, [25..30] latest end by stop shell
+  uint32_t nq;                 // queries of the launch
+  uint32_t* ticket;            // k-NN: persistent blocks draw their queries here (zero at launch); null = block b serves query b
+  uint32_t use_lines;          // k-NN, 32-bit substrings: probe the directory lines (VcTableView::lines) instead of bitmap + blockoff + offsets
   uint32_t group;              // k-NN, 32-bit substrings: shells 0 .. group-1 share the first pass (1 = one shell per pass)
   uint32_t* radius_hist;       // k-NN: [4] queries of the launch by the shell they stopped in (0, 1, 2, later / handed over)
 };
@@ -785,7 +882,7 @@ __device__ __noinline__ void mq_select_exact(uint64_t* s_buf, uint32_t* s_ncand,
   __syncthreads();
 }
 
-template <int W, uint32_t MQ_LO>
+template <int W, uint32_t MQ_LO, bool LINES>
 __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kernel(const QueryKernelParams p) {
   constexpr uint32_t MQ_HI = 32u - MQ_LO;
   constexpr uint32_t MQ_GW = (1u << MQ_LO) / 32u;                    // 32-bit words per granule
@@ -810,7 +907,16 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   __shared__ uint32_t s_segstart[28], s_segh[27], s_segmask[27], s_segr[27], s_nseg;
   __shared__ uint64_t s_thresh;
 
+  __shared__ unsigned long long s_t_entry;   // dev (VC_MIH_PHASES): thread 0's clock at entry -- in LDS, not in a register pair that lives to the end
+  __shared__ unsigned long long s_ph_last;
+  __shared__ uint32_t s_ph_cur;
+  __shared__ unsigned long long s_stat[5];
+#if MQ_PERSISTENT
+  __shared__ uint32_t s_slot;
+  uint32_t slot = blockIdx.x;
+#else
   const uint32_t slot = blockIdx.x;
+#endif
   const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
   const uint32_t s = p.sbits, m = p.m;
   const uint32_t smask = s == 32 ? 0xFFFFFFFFu : ((1u << s) - 1u);
@@ -823,12 +929,24 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     asm volatile("" : "+s"(q));   // opaque: the loads stay behind this point
     return q;
   };
-  __shared__ unsigned long long s_t_entry;   // dev (VC_MIH_PHASES): thread 0's clock at entry -- in LDS, not in a register pair that lives to the end
+  // per block, once: the tables' views (directory lines: a granule is then the first 16 bytes of its key range's 64-byte line,
+  // MQ_LO = 7 <=> 128 keys per line)
+  constexpr uint32_t gstride = LINES ? 16u : MQ_GW;   // words between consecutive granules
+  for (uint32_t i = tid; i < m * (sizeof(VcTableView) / 4); i += MQ_BLK) ((uint32_t*)s_tv)[i] = ((const uint32_t*)p.tables)[i];
+  if (LINES) {
+    __syncthreads();
+    if (tid < m) s_tv[tid].bitmap = (const uint32_t*)s_tv[tid].lines;
+  }
+
+  // ---- one query, start to end (a persistent block runs this for every query it draws)
+#if MQ_PERSISTENT
+  auto run_query = [&]() __attribute__((always_inline)) {
+#endif
   if (p.phase_dbg && threadIdx.x == 0) s_t_entry = __builtin_amdgcn_s_memrealtime();
 
   uint64_t qw[W];
 #pragma unroll
-  for (int j = 0; j < W; ++j) qw[j] = p.queries[(uint64_t)slot * W + j];
+  for (int j = 0; j < W; ++j) qw[j] = (MQ_PERSISTENT ? cold()->queries : p.queries)[(uint64_t)slot * W + j];
   auto qkey = [&](uint32_t t) {
     const uint32_t bp = t * s;
     uint32_t v = 0;
@@ -838,8 +956,12 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     return v;
   };
 
-  for (uint32_t i = tid; i < 33 * MQ_BW; i += MQ_BLK) s_binom[i] = c_binom[i / MQ_BW][i % MQ_BW];
-  for (uint32_t i = tid; i < m * (sizeof(VcTableView) / 4); i += MQ_BLK) ((uint32_t*)s_tv)[i] = ((const uint32_t*)p.tables)[i];
+  // the binomial table feeds combination unranking beyond the closed forms (|hi| >= 3: shells >= 3) and the <= 16-bit key
+  // walk; a 32-bit k-NN query that stops in shells 0..2 -- most do -- never reads it, so it is copied when first needed
+  auto load_binom = [&]() {         // (the barrier at the top of plan32 / before the first scan publishes it)
+    for (uint32_t i = tid; i < 33 * MQ_BW; i += MQ_BLK) s_binom[i] = c_binom[i / MQ_BW][i % MQ_BW];
+  };
+  if (s != 32 || !knn || !MQ_LAZY_BINOM) load_binom();
   if (s == 32)
     for (uint32_t i = tid; i < m * MQ_NJ * MQ_GW; i += MQ_BLK) s_mask[i] = 0;
   if (knn)
@@ -879,8 +1001,6 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   // distance histogram in LDS (no sort per shell: the bitonic network after every shell was most of this kernel's
   // instructions); the buffer is compacted when it fills and sorted once, when the query ends or is handed over.
   // VC_MIH_PHASES (dev): where a block's time goes -- phase times in 10 ns ticks, summed per phase over the launch
-  __shared__ unsigned long long s_ph_last;
-  __shared__ uint32_t s_ph_cur;
   auto tick = [&](uint32_t next) {   // ends the current phase, starts `next`
     if (p.phase_dbg && tid == 0) {
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -900,7 +1020,6 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   uint32_t ring_fill = 0;          // radius mode: entries already in the global ring       (block-uniform)
   // get_stat counters of table 0 (sub, loc) and the algorithmic work of this query (probes, non-empty buckets, entries): thread 0's,
   // in LDS -- as block-uniform locals they were ten more scalar registers alive from entry to exit
-  __shared__ unsigned long long s_stat[5];
   unsigned long long& sub = s_stat[0];
   unsigned long long& loc = s_stat[1];
   unsigned long long& w_probes = s_stat[2];
@@ -976,7 +1095,24 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     __syncthreads();
     tick(2);
     const uint32_t H = min(s_nh, MQ_HMAX);
-    if (s == 32) {
+    if (LINES && s == 32) {
+      // directory lines: occupancy, first entry position, rank and the buckets' extents sit in the ONE sector the scan just
+      // read (four 16-byte loads that hit L2); only a line whose buckets fit neither encoding goes on to offsets[]
+      for (uint32_t i = tid; i < H; i += MQ_BLK) {
+        const uint32_t key = s_key[i];
+        const VcTableView& tv = s_tv[s_meta[i] & 0xFFu];
+        const uint4* ln = tv.lines + (uint64_t)(key >> 7) * 4;
+        const uint4 occ = ln[0], dir = ln[1], f0 = ln[2], f1 = ln[3];
+        uint32_t a, len, rk;
+        if (!vc_line_lookup(occ, dir, f0, f1, key & 127u, a, len, rk)) {
+          a = tv.offsets[rk];
+          len = tv.offsets[rk + 1] - a;
+        }
+        s_key[i] = a;
+        s_pref[i] = len;
+      }
+      __syncthreads();
+    } else if (!LINES && s == 32) {
       for (uint32_t i = tid; i < H; i += MQ_BLK) {
         const uint32_t key = s_key[i];
         const VcTableView& tv = s_tv[s_meta[i] & 0xFFu];
@@ -1181,7 +1317,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           }
           gr[g] = (qkey(t) >> MQ_LO) ^ hi;
           meta0[g] = t | (s_segh[seg] << 8) | (s_segmask[seg] << 16) | ((s_segr[seg] - r_base) << 30);   // bits 30..31: shell class of the segment
-          const uint4* gp = reinterpret_cast<const uint4*>(s_tv[t].bitmap + (uint64_t)gr[g] * MQ_GW);
+          const uint4* gp = reinterpret_cast<const uint4*>(s_tv[t].bitmap + (uint64_t)gr[g] * gstride);
 #pragma unroll
           for (uint32_t c = 0; c < MQ_GW / 4; ++c) v[g][c] = gp[c];
         }
@@ -1337,7 +1473,8 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           s_segh[ns] = h;
           s_segmask[ns] = min(j, MQ_LO);
           s_segr[ns] = r;
-          start += s_binom[MQ_HI * MQ_BW + h];
+          // C(MQ_HI, h): closed form while the LDS table may not exist yet (it is copied before the pass of shell 3)
+          start += h == 0 ? 1u : (h == 1 ? MQ_HI : (h == 2 ? MQ_HI * (MQ_HI - 1u) / 2u : s_binom[MQ_HI * MQ_BW + h]));
           ++ns;
         }
       s_segstart[ns] = start;
@@ -1404,6 +1541,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     const uint32_t r_hi = (s == 32 && r == 0) ? min(p.group ? p.group - 1 : 0u, min(p.r_last, MQ_MAX_GROUP - 1)) : r;
     r_base = r;
     if (s == 32) {
+      if (MQ_LAZY_BINOM && r_hi >= 3) load_binom();   // (again for every later shell: 561 words next to a pass of >= 10 504 granules)
       plan32(r, r_hi, false);
       scan32();
     } else {
@@ -1520,6 +1658,27 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       atomicMax(&p.phase_dbg[30], now);
     }
   }
+#if MQ_PERSISTENT
+  };   // run_query
+#endif
+
+  // Persistent form (k-NN launches): the grid is one residency wave and every block draws queries from a ticket counter until
+  // they are gone -- a workgroup launch per query (LDS allocation, wave start, kernel-argument and table reads) cost the
+  // slots a fifth of their time (r04: the blocks' lifetimes summed to 62 % of slots x kernel time).
+  // (ONE call site: called from two places the body became a function of its own, closure and all in scratch)
+#if MQ_PERSISTENT
+  for (;;) {
+    if (cold()->ticket) {
+      __syncthreads();                    // the previous query's LDS state is dead
+      if (tid == 0) s_slot = atomicAdd(cold()->ticket, 1u);
+      __syncthreads();
+      slot = __builtin_amdgcn_readfirstlane(s_slot);   // (scalar: addresses derived from it stay scalar)
+      if (slot >= cold()->nq) return;
+    }
+    run_query();
+    if (!cold()->ticket) return;
+  }
+#endif
 }
 
 // =============================================================================================================
@@ -2171,6 +2330,18 @@ void vc_mih_free(VcMihIndex* ix) {
   delete ix;
 }
 
+// directory lines (VcTableView::lines): 2 GB per 32-bit table, built while that is a small part of what is still free once the
+// records of the index itself (ids, offsets, bitmaps, directories, {id, code} records) have their room (VC_MIH_LINES=0/1 overrides)
+#define MIH_NLINES (1u << 25)
+static bool want_dir_lines(uint32_t sbits, uint32_t m, uint64_t n, uint32_t W, bool want_bent, const VcKnobs& knobs) {
+  if (sbits != 32 || n == 0) return false;
+  if (knobs.mih_lines >= 0) return knobs.mih_lines != 0;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  const size_t index_bytes = (size_t)m * (n * 8 + (1ull << 29) + (3ull << 26)) + (want_bent ? (size_t)m * n * 16 * W : 0);
+  return free_b > index_bytes && (size_t)m * MIH_NLINES * 64 <= (free_b - index_bytes) / 4;
+}
+
 int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint64_t n, uint32_t W, uint32_t m,
                  uint32_t sbits, uint32_t id_base, uint32_t flags, uint32_t n_cu, uint32_t cand_cap, const VcKnobs& knobs,
                  hipStream_t s, std::string* err) {
@@ -2206,6 +2377,7 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
     if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 * W > free_b / 100 * 55) want_bent = false;   // (55 % of the free memory: 128 GB of records at 1e9 x 128 bit next to 50 GB of codes + index on a 288 GB part)
     if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W <= 2;
   }
+  const bool want_lines = want_dir_lines(sbits, m, n, W, want_bent, knobs);
   const uint64_t nkeyspace = 1ull << sbits;
   const uint64_t bm_words = std::max<uint64_t>(nkeyspace / 32, 8);
   const uint32_t mask = sbits == 32 ? 0xFFFFFFFFu : (uint32_t)(nkeyspace - 1);
@@ -2285,6 +2457,13 @@ int vc_mih_build(VcMihIndex** out, const uint64_t* d_cols, uint64_t stride, uint
       hipLaunchKernelGGL(mih_blockoff_kernel, dim3(n_cu * 16), dim3(256), 0, s, blockrank, offsets, nblocks, tv.n_unique, blockoff);
       B_CHECK(hipGetLastError());
       tv.blockoff = blockoff;
+      if (want_lines) {
+        uint4* lines = nullptr;
+        B_CHECK(dalloc((void**)&lines, (size_t)MIH_NLINES * 64, true));
+        hipLaunchKernelGGL(mih_lines_kernel, dim3(n_cu * 16), dim3(256), 0, s, bitmap, blockrank, offsets, MIH_NLINES, lines);
+        B_CHECK(hipGetLastError());
+        tv.lines = lines;
+      }
     }
     tv.offsets = offsets;
     tv.ids = ids;
@@ -2557,6 +2736,7 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
     if (want_bent && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)m * n * 16 * W > free_b / 100 * 55) want_bent = false;   // (55 % of the free memory: 128 GB of records at 1e9 x 128 bit next to 50 GB of codes + index on a 288 GB part)
     if (knobs.mih_bent >= 0) want_bent = knobs.mih_bent != 0 && sbits == 32 && W <= 2;
   }
+  const bool want_lines = want_dir_lines(sbits, m, n, W, want_bent, knobs);
   auto dalloc = [&](void** p, size_t bytes) -> int {
     hipError_t r = hipMalloc(p, std::max<size_t>(bytes, 256));
     if (r != hipSuccess) {
@@ -2642,6 +2822,12 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
       if ((rc = dalloc((void**)&blockoff, ((size_t)(1u << 24) + 1) * 8))) break;
       hipLaunchKernelGGL(mih_blockoff_kernel, dim3(n_cu * 16), dim3(256), 0, s, blockrank, offsets, 1u << 24, tv.n_unique, blockoff);
       tv.blockoff = blockoff;
+      if (want_lines) {
+        uint4* lines = nullptr;
+        if ((rc = dalloc((void**)&lines, (size_t)MIH_NLINES * 64))) break;
+        hipLaunchKernelGGL(mih_lines_kernel, dim3(n_cu * 16), dim3(256), 0, s, bitmap, blockrank, offsets, MIH_NLINES, lines);
+        tv.lines = lines;
+      }
     }
     if (want_bcodes && n) {
       uint64_t* bc = nullptr;
@@ -2737,12 +2923,30 @@ static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits,
          (size_t)m * sizeof(VcTableView) + 16;                                                   // the tables' views
 }
 
-static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s) {
+// grid of a launch: one block per query, or -- persistent form (p.ticket) -- one residency wave of blocks that draw their queries
+template <class K>
+static uint32_t query_grid(K kernel, const QueryKernelParams& p, size_t lds, uint32_t nq, uint32_t n_cu) {
+  if (!p.ticket) return nq;
+  static thread_local struct { const void* fn; size_t lds; int occ; } cache[8] = {};
+  int occ = 0;
+  for (auto& c : cache)
+    if (c.fn == (const void*)kernel && c.lds == lds) occ = c.occ;
+  if (occ == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, (int)MQ_BLK, lds) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 1; }
+    for (auto& c : cache)
+      if (!c.fn) { c.fn = (const void*)kernel; c.lds = lds; c.occ = occ; break; }
+  }
+  return (uint32_t)std::min<uint64_t>(nq, (uint64_t)occ * std::max(n_cu, 1u));
+}
+
+static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s, uint32_t n_cu = 0) {
   const size_t lds = query_kernel_lds(p.buf_entries, p.m, p.sbits, W);
+#define MQ_LAUNCH_K(K_) hipLaunchKernelGGL((K_), dim3(query_grid((K_), p, lds, nq, n_cu)), dim3(MQ_BLK), lds, s, p)
 #define MQ_LAUNCH(W_)                                                                                           \
   case W_:                                                                                                      \
-    if (p.mode == MQ_MODE_RADIUS) hipLaunchKernelGGL((mih_query_kernel<W_, MQ_LO_RADIUS>), dim3(nq), dim3(MQ_BLK), lds, s, p); \
-    else hipLaunchKernelGGL((mih_query_kernel<W_, MQ_LO_KNN>), dim3(nq), dim3(MQ_BLK), lds, s, p);              \
+    if (p.mode == MQ_MODE_RADIUS) MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_RADIUS, false>));                     \
+    else if (p.use_lines && MQ_LO_KNN == 7u) MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_KNN, MQ_LO_KNN == 7u>));   \
+    else MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_KNN, false>));                                                 \
     break;
   switch (W) {
     MQ_LAUNCH(1)
@@ -2752,6 +2956,7 @@ static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, ui
     default: return hipErrorInvalidValue;
   }
 #undef MQ_LAUNCH
+#undef MQ_LAUNCH_K
   return hipGetLastError();
 }
 
@@ -2783,7 +2988,7 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
     if (ix->ev_used < ix->ev_pool.size()) ev = &ix->ev_pool[ix->ev_used++];
   }
   if (ev) (void)hipEventRecord(ev->first, s);
-  hipError_t r = launch_query_kernel(p, W, nq, s);
+  hipError_t r = launch_query_kernel(p, W, nq, s, ix->n_cu);
   if (ev) (void)hipEventRecord(ev->second, s);
   if (r != hipSuccess) return r;
   // (k-NN launches: heavy_ctr = the tile's counter block + 2.  Radius search has no counters to publish, and its work
@@ -2965,6 +3170,9 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       qp.mode = approximate ? MQ_MODE_APPROX : MQ_MODE_EXACT; qp.stop_mult = stop_mult; qp.r_last = r_last;
       qp.buf_entries = buf_entries; qp.heavy_list = cur; qp.heavy_ctr = d_ctr + 2;
       qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0; qp.group = group; qp.radius_hist = d_ctr + 4;
+      qp.use_lines = (S == 32 && !ix->h_tables.empty() && ix->h_tables[0].lines) ? 1u : 0u;
+      qp.nq = qt;
+      qp.ticket = (MQ_PERSISTENT && ix->knobs.mih_persistent) ? d_ctr + 3 : nullptr;   // (zero: memset above / re-zeroed by every reduce kernel)
       const auto t_q = std::chrono::steady_clock::now();
       if (!ix->h_ctr_dev) MIH_CHECK(hipMemsetAsync(d_ctr, 0, 32, s));   // (else zeroed at allocation and by every reduce kernel since)
       MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));

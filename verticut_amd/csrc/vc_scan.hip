@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
       const uint64_t v = a[i];
       uint32_t r = 0;
       if (v != VC_PACK_INF) {
-        for (uint32_t j = 0; j < P; ++j) r += a[j] < v;
+        for (uint32_t j = 0; j < P; ++j) r += a[j] < v || (a[j] == v && j < i);   // (equal values -- gathered lists that overlap -- keep distinct slots)
       } else {
         r = i;   // padding sits at the tail of a[] already (index >= fill) and stays there
       }
