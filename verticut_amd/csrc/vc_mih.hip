@@ -1190,6 +1190,9 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         }
       }
       const uint64_t thresh = s_thresh;
+      // a wave none of whose lanes has an entry in this round (the tail round of a drain: 1 055 entries are one full round
+      // and 31 entries for wave 0) has nothing to search, load or verify -- entry e0 + wave * 64 is its first
+      if (e0 + wave * VC_WAVE >= total) continue;
       uint32_t local[MQ_EPT], meta[MQ_EPT];
       uint64_t x[MQ_EPT][W];
       bool live[MQ_EPT];
@@ -1704,6 +1707,9 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 #ifndef MS_STAGE
 #define MS_STAGE 128u                     // results a wave stages in LDS between two flushes (>= 128)
 #endif
+#ifndef MS_SEGMENTS
+#define MS_SEGMENTS 1                    // the wave's buckets as one stream of 128-entry segments (0: bucket by bucket, round 3)
+#endif
 #ifndef MS_MAXP
 #define MS_MAXP 2048u                    // probes of one query (all tables, all shells) held in LDS
 #endif
@@ -1837,6 +1843,67 @@ __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamPara
   // even positions 16-byte aligned (one-word codes, or an even entry count); the copies are padded by one entry so that the
   // pair that holds the table's last entry stays inside the allocation
   const bool pairs = W == 1 || (p.n & 1ull) == 0;
+#if MS_SEGMENTS
+  if (pairs) {
+    // The wave's buckets as ONE stream of 128-entry segments (64 lanes x one 16-byte pair), MS_UP segments in flight whatever
+    // bucket they belong to.  Bucket by bucket, a 1 526-entry bucket (1e8 codes, 16-bit substrings) took two rounds of 1 024
+    // lane slots -- the second one half empty, its idle lanes re-reading the bucket's first pair: a quarter of the kernel's
+    // load instructions fetched nothing new (r03: 0.67 of the HBM peak for a pure stream).  Now only a bucket's LAST segment
+    // has idle lanes (4 % of the slots at that size).
+    uint32_t b = wave, cur = 0, bend = 0, boff = 0, bmeta = 0;        // cursor: bucket b, next pair-aligned position cur (wave-uniform)
+    auto open_bucket = [&]() -> bool {                               // first non-empty bucket at or behind b
+      for (; b < nloc; b += blockDim.x / VC_WAVE) {
+        const uint32_t len = __builtin_amdgcn_readfirstlane(s_len[b]);   // (b is wave-uniform: scalar cursor, scalar segment records)
+        if (len) {
+          boff = __builtin_amdgcn_readfirstlane(s_off[b]);
+          bend = boff + len;
+          cur = boff & ~1u;
+          bmeta = __builtin_amdgcn_readfirstlane(s_meta[b]);
+          return true;
+        }
+      }
+      return false;
+    };
+    bool have = open_bucket();
+    while (have) {
+      vc_u64x2 v[MS_UP][W];
+      uint32_t g_start[MS_UP], g_off[MS_UP], g_end[MS_UP], g_meta[MS_UP];   // the segments of this round (wave-uniform)
+      uint32_t nseg = 0;
+#pragma unroll
+      for (uint32_t u = 0; u < MS_UP; ++u) {
+        g_start[u] = cur; g_off[u] = boff; g_end[u] = bend; g_meta[u] = bmeta;
+        if (have) {
+          const uint64_t* bc = p.tables[bmeta & 0xFFu].bcodes;
+          const uint32_t pa = cur + 2 * lane;
+          const uint32_t pc = pa < bend ? pa : (boff & ~1u);           // clamp: the bucket's first pair exists
+#pragma unroll
+          for (int j = 0; j < W; ++j) v[u][j] = __builtin_nontemporal_load(reinterpret_cast<const vc_u64x2*>(bc + (uint64_t)j * p.n + pc));
+          nseg = u + 1;
+          cur += 2 * VC_WAVE;
+          if (cur >= bend) {
+            b += blockDim.x / VC_WAVE;
+            have = open_bucket();
+          }
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < MS_UP; ++u) {
+        if (u >= nseg) break;
+        const uint32_t pa = g_start[u] + 2 * lane;
+        uint64_t xa[W], xb[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          xa[j] = v[u][j].x;
+          xb[j] = v[u][j].y;
+        }
+        entry(xa, pa >= g_off[u] && pa < g_end[u], pa, g_meta[u] & 0xFFu, g_meta[u] >> 8);
+        entry(xb, pa + 1 < g_end[u], pa + 1, g_meta[u] & 0xFFu, g_meta[u] >> 8);   // (pa + 1 > off always)
+      }
+    }
+    if (fill) flush();
+    return;
+  }
+#endif
   for (uint32_t b = wave; b < nloc; b += blockDim.x / VC_WAVE) {
     const uint32_t off = s_off[b], len = s_len[b], t = s_meta[b] & 0xFFu, dt = s_meta[b] >> 8;
     if (len == 0) continue;
@@ -2336,6 +2403,10 @@ void vc_mih_free(VcMihIndex* ix) {
 static bool want_dir_lines(uint32_t sbits, uint32_t m, uint64_t n, uint32_t W, bool want_bent, const VcKnobs& knobs) {
   if (sbits != 32 || n == 0) return false;
   if (knobs.mih_lines >= 0) return knobs.mih_lines != 0;
+  // Where most 256-key blocks hold single-entry buckets only (93 % at 1e8 codes) the block directory answers a hit in one round
+  // trip too and the lines gain nothing (r04, same box: 13.7 vs 13.6 M queries/s at 1e8, 9.96 -> 10.25 M at 1e9): build them from
+  // the size on where a block's buckets are rarely all single (n / 2^32 = 0.07: a third of the blocks)
+  if (n < 300000000ull) return false;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
   const size_t index_bytes = (size_t)m * (n * 8 + (1ull << 29) + (3ull << 26)) + (want_bent ? (size_t)m * n * 16 * W : 0);
@@ -2939,12 +3010,12 @@ static uint32_t query_grid(K kernel, const QueryKernelParams& p, size_t lds, uin
   return (uint32_t)std::min<uint64_t>(nq, (uint64_t)occ * std::max(n_cu, 1u));
 }
 
-static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s, uint32_t n_cu = 0) {
+static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s, uint32_t n_cu = 0, bool wide = false) {
   const size_t lds = query_kernel_lds(p.buf_entries, p.m, p.sbits, W);
 #define MQ_LAUNCH_K(K_) hipLaunchKernelGGL((K_), dim3(query_grid((K_), p, lds, nq, n_cu)), dim3(MQ_BLK), lds, s, p)
 #define MQ_LAUNCH(W_)                                                                                           \
   case W_:                                                                                                      \
-    if (p.mode == MQ_MODE_RADIUS) MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_RADIUS, false>));                     \
+    if (p.mode == MQ_MODE_RADIUS || wide) MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_RADIUS, false>));             \
     else if (p.use_lines && MQ_LO_KNN == 7u) MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_KNN, MQ_LO_KNN == 7u>));   \
     else MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_KNN, false>));                                                 \
     break;
@@ -2988,7 +3059,10 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
     if (ix->ev_used < ix->ev_pool.size()) ev = &ix->ev_pool[ix->ev_used++];
   }
   if (ev) (void)hipEventRecord(ev->first, s);
-  hipError_t r = launch_query_kernel(p, W, nq, s, ix->n_cu);
+  // approximate k-NN walks deep shells (20 k candidates: mean radius ~4 on the bench data = 10 ^ 5 probes per query), where a
+  // 64-byte granule -- one whole sector, as in the radius search -- takes fewer sectors than 16-byte ones (dev knob VC_MIH_APPROX_WIDE)
+  const bool wide = p.mode == MQ_MODE_APPROX && p.sbits == 32 && ix->knobs.mih_approx_wide;
+  hipError_t r = launch_query_kernel(p, W, nq, s, ix->n_cu, wide);
   if (ev) (void)hipEventRecord(ev->second, s);
   if (r != hipSuccess) return r;
   // (k-NN launches: heavy_ctr = the tile's counter block + 2.  Radius search has no counters to publish, and its work

@@ -830,17 +830,27 @@ __global__ void __launch_bounds__(VC_SEL_THREADS) vc_select_kernel(Src src, uint
   // instead of the ~log^2 P barriers of the bitonic network.
   const uint64_t* sorted = a;
   if (P <= VC_RANK_SORT_MAX) {
+    // All 1024 threads count: VC_SEL_THREADS / P threads share an entry, each walks its slice of a[] (the usual few hundred
+    // survivors used to leave three quarters of the block idle while P threads walked all of a[]: 4 of the kernel's 10 us)
+    // and the partial ranks meet in hist[] (free here).
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < P; i += VC_SEL_THREADS) {
-      const uint64_t v = a[i];
+    const uint32_t parts = min(VC_SEL_THREADS / P, P);         // P is a power of two, 2 .. 1024: 1 <= parts <= P, both powers of two
+    const uint32_t i = threadIdx.x & (P - 1u), part = threadIdx.x / P;
+    const uint32_t j0 = part * (P / parts), j1 = j0 + P / parts;
+    if (threadIdx.x < P) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t v = a[i];
+    if (part >= parts) {
+      // (more threads than entry x slice pairs: nothing to do)
+    } else if (v != VC_PACK_INF) {
       uint32_t r = 0;
-      if (v != VC_PACK_INF) {
-        for (uint32_t j = 0; j < P; ++j) r += a[j] < v || (a[j] == v && j < i);   // (equal values -- gathered lists that overlap -- keep distinct slots)
-      } else {
-        r = i;   // padding sits at the tail of a[] already (index >= fill) and stays there
-      }
-      srt[r] = v;
+      for (uint32_t j = j0; j < j1; ++j) r += a[j] < v || (a[j] == v && j < i);   // (equal values -- gathered lists that overlap -- keep distinct slots)
+      if (parts > 1) atomicAdd(&hist[i], r); else hist[i] = r;
+    } else if (part == 0) {
+      hist[i] = i;   // padding sits at the tail of a[] already (index >= fill) and stays there
     }
+    __syncthreads();
+    if (threadIdx.x < P) srt[hist[threadIdx.x]] = a[threadIdx.x];
     __syncthreads();
     sorted = srt;
   } else {
