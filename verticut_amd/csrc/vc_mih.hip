@@ -1707,9 +1707,6 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 #ifndef MS_STAGE
 #define MS_STAGE 128u                     // results a wave stages in LDS between two flushes (>= 128)
 #endif
-#ifndef MS_SEGMENTS
-#define MS_SEGMENTS 1                    // the wave's buckets as one stream of 128-entry segments (0: bucket by bucket, round 3)
-#endif
 #ifndef MS_MAXP
 #define MS_MAXP 2048u                    // probes of one query (all tables, all shells) held in LDS
 #endif
@@ -1843,67 +1840,10 @@ __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamPara
   // even positions 16-byte aligned (one-word codes, or an even entry count); the copies are padded by one entry so that the
   // pair that holds the table's last entry stays inside the allocation
   const bool pairs = W == 1 || (p.n & 1ull) == 0;
-#if MS_SEGMENTS
-  if (pairs) {
-    // The wave's buckets as ONE stream of 128-entry segments (64 lanes x one 16-byte pair), MS_UP segments in flight whatever
-    // bucket they belong to.  Bucket by bucket, a 1 526-entry bucket (1e8 codes, 16-bit substrings) took two rounds of 1 024
-    // lane slots -- the second one half empty, its idle lanes re-reading the bucket's first pair: a quarter of the kernel's
-    // load instructions fetched nothing new (r03: 0.67 of the HBM peak for a pure stream).  Now only a bucket's LAST segment
-    // has idle lanes (4 % of the slots at that size).
-    uint32_t b = wave, cur = 0, bend = 0, boff = 0, bmeta = 0;        // cursor: bucket b, next pair-aligned position cur (wave-uniform)
-    auto open_bucket = [&]() -> bool {                               // first non-empty bucket at or behind b
-      for (; b < nloc; b += blockDim.x / VC_WAVE) {
-        const uint32_t len = __builtin_amdgcn_readfirstlane(s_len[b]);   // (b is wave-uniform: scalar cursor, scalar segment records)
-        if (len) {
-          boff = __builtin_amdgcn_readfirstlane(s_off[b]);
-          bend = boff + len;
-          cur = boff & ~1u;
-          bmeta = __builtin_amdgcn_readfirstlane(s_meta[b]);
-          return true;
-        }
-      }
-      return false;
-    };
-    bool have = open_bucket();
-    while (have) {
-      vc_u64x2 v[MS_UP][W];
-      uint32_t g_start[MS_UP], g_off[MS_UP], g_end[MS_UP], g_meta[MS_UP];   // the segments of this round (wave-uniform)
-      uint32_t nseg = 0;
-#pragma unroll
-      for (uint32_t u = 0; u < MS_UP; ++u) {
-        g_start[u] = cur; g_off[u] = boff; g_end[u] = bend; g_meta[u] = bmeta;
-        if (have) {
-          const uint64_t* bc = p.tables[bmeta & 0xFFu].bcodes;
-          const uint32_t pa = cur + 2 * lane;
-          const uint32_t pc = pa < bend ? pa : (boff & ~1u);           // clamp: the bucket's first pair exists
-#pragma unroll
-          for (int j = 0; j < W; ++j) v[u][j] = __builtin_nontemporal_load(reinterpret_cast<const vc_u64x2*>(bc + (uint64_t)j * p.n + pc));
-          nseg = u + 1;
-          cur += 2 * VC_WAVE;
-          if (cur >= bend) {
-            b += blockDim.x / VC_WAVE;
-            have = open_bucket();
-          }
-        }
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < MS_UP; ++u) {
-        if (u >= nseg) break;
-        const uint32_t pa = g_start[u] + 2 * lane;
-        uint64_t xa[W], xb[W];
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          xa[j] = v[u][j].x;
-          xb[j] = v[u][j].y;
-        }
-        entry(xa, pa >= g_off[u] && pa < g_end[u], pa, g_meta[u] & 0xFFu, g_meta[u] >> 8);
-        entry(xb, pa + 1 < g_end[u], pa + 1, g_meta[u] & 0xFFu, g_meta[u] >> 8);   // (pa + 1 > off always)
-      }
-    }
-    if (fill) flush();
-    return;
-  }
-#endif
+  // (r04: the wave's buckets as ONE stream of 128-entry segments -- no half-empty second round per 1 526-entry bucket, 4 % idle
+  // lane slots instead of 25 % -- was built and is 23 % SLOWER, 0.563 against 0.435 ms per launch on one box: the idle lanes'
+  // clamped loads hit the cache and cost next to nothing, while a cursor that crosses bucket boundaries puts LDS reads and
+  // scalar bookkeeping between the loads of a round.  What bounds the kernel is the run length: profiles/r04_stream_runs.txt)
   for (uint32_t b = wave; b < nloc; b += blockDim.x / VC_WAVE) {
     const uint32_t off = s_off[b], len = s_len[b], t = s_meta[b] & 0xFFu, dt = s_meta[b] >> 8;
     if (len == 0) continue;
