@@ -1089,6 +1089,12 @@ def run_sharded1dev(args, env, emit):
         bare(i)
     env.sync()
     _, bare_elapsed = timed_steps(env, lambda c: [bare(i) for i in range(c)], args.steps)
+    # the two forms alternate twice more: the layer's cost is a difference of two ~3 ms figures, a drifting clock shows in it
+    pairs = []
+    for _ in range(2):
+        _, a = timed_steps(env, lambda c: [one(i) for i in range(c)], args.steps)
+        _, b = timed_steps(env, lambda c: [bare(i) for i in range(c)], args.steps)
+        pairs.append(((a - b) / args.steps * 1e6, a / args.steps * 1e3, b / args.steps * 1e3))
     ok = True
     if not args.no_check:    # the sharded rows == merge of the bare shard rows of the same batch, distances recomputed from the stored codes
         qi = (args.steps - 1) % 4
@@ -1121,6 +1127,8 @@ def run_sharded1dev(args, env, emit):
         "sharded_layer": {
             "ms_per_batch": ms, "sum_of_shard_scan_kernel_ms": sum_scan, "shard_scan_kernel_ms": scan_avgs,
             "same_engines_without_the_layer_ms": bare_ms, "layer_overhead_us": (ms - bare_ms) * 1e3,
+            "layer_overhead_us_repeats": [round(p[0], 1) for p in pairs],   # two more alternating (layer, bare) pairs of `steps` batches
+            "layer_overhead_us_median": float(np.median([(ms - bare_ms) * 1e3] + [p[0] for p in pairs])),
             "around_the_verify_kernels_us": (ms - sum_scan) * 1e3, "host_enqueue_ms_per_batch": host_issue_ms,
             "what": "layer_overhead_us = ms_per_batch - the same %d shard engines driven back to back on the same stream without exchange / merge; "
                     "around_the_verify_kernels_us also holds every shard's bootstrap / select / recover launches" % G,

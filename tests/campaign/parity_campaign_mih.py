@@ -83,8 +83,11 @@ def main():
             bits, s, n, centres, flips, k, nq, flag, approx)
         # every fifth case sends the exact loop through the verify kernel + replayed stop rule (the cost-model switch, forced),
         # another fifth sends <= 16-bit radius searches through the bucket streaming kernel (knobs are read at vc_create)
-        for kn in ("VC_MIH_SWITCH", "VC_MIH_HOST_LOOP", "VC_MIH_STREAM"):
+        for kn in ("VC_MIH_SWITCH", "VC_MIH_HOST_LOOP", "VC_MIH_STREAM", "VC_MIH_LINES"):
             os.environ.pop(kn, None)
+        if s == 32 and i % 3 == 0:       # directory lines (built by default only from 3e8 records on): every third 32-bit case
+            os.environ["VC_MIH_LINES"] = "1"
+            desc += " [lines]"
         if i % 5 == 3:
             os.environ.update(VC_MIH_SWITCH="2", VC_MIH_HOST_LOOP="1")
             desc += " [switch]"

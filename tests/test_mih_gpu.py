@@ -614,3 +614,57 @@ def test_work_counters_of_the_bucket_streaming_kernel(vc, oracle, monkeypatch):
         e.search_radius(q, 8, mode=vc.MODE_MIH_EXACT)
         t = e.timing()
         assert (t.mih_queries, t.mih_probes) == (len(q), len(q) * 188) and t.mih_entries >= t.mih_hits > 0
+
+
+@pytest.mark.parametrize("bits,m", [(128, 4), (64, 2)])
+def test_directory_lines_every_encoding(vc, oracle, monkeypatch, bits, m):
+    """Directory lines of the 32-bit tables (VcTableView::lines: occupancy + first entry position + rank + bucket extents of 128
+    keys in ONE 64-byte sector; built by default only from 3e8 records on, forced here) against the oracle's
+    SearchWorker::find (search_worker.cc:159-264), on data made to hit every encoding of a line: cumulative 16-bit ends
+    (<= 16 buckets, some of them long: clusters), 2-bit lengths (dense key ranges whose buckets hold <= 4 entries), the
+    fall-back to offsets[rank] (dense ranges with longer buckets), empty lines; exact and approximate mode, statistics,
+    bucket views; the same queries with the lines off give the same rows."""
+    rng = np.random.default_rng(bits)
+    parts = []
+    def region(count, lo, span):                       # substrings drawn from [lo, lo + span): density decides the encoding
+        return (lo + rng.integers(0, span, size=(count, m))).astype(np.uint32)
+    parts.append(region(900, 0, 1 << 10))                                 # ~0.9 entries per key, ~75 buckets per line: 2-bit lengths
+    parts.append(region(4000, 1 << 12, 1 << 9))                           # ~8 per key, 128 buckets per line: fall-back
+    centres = rng.integers(0, 1 << 32, size=(40, m), dtype=np.uint64)
+    pick = rng.integers(0, 40, size=6000)
+    parts.append(((centres[pick] ^ rng.integers(0, 8, size=(6000, m)).astype(np.uint64)) & np.uint64(0xFFFFFFFF)).astype(np.uint32))   # clusters: <= 8 long buckets per line
+    parts.append(rng.integers(0, 1 << 32, size=(5000, m), dtype=np.uint64).astype(np.uint32))                                           # sparse singles
+    sub = np.concatenate(parts)
+    n_near = sub.shape[0] - 5000                       # queries come from the dense ranges and the clusters (the oracle walks a far
+    perm = rng.permutation(sub.shape[0])               # query's shells one key at a time)
+    codes = np.ascontiguousarray(sub[perm]).view(np.uint8).reshape(sub.shape[0], bits // 8)
+    n, k = codes.shape[0], 15
+    near = np.nonzero(perm < n_near)[0]
+    q = codes[rng.choice(near, size=24, replace=False)].copy()
+    for r in range(len(q)):
+        for b in rng.choice(bits, size=int(rng.integers(0, 3)), replace=False):
+            q[r, b // 8] ^= np.uint8(1 << (b % 8))
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    rows = {}
+    for lines in ("1", "0"):
+        monkeypatch.setenv("VC_MIH_LINES", lines)
+        with vc.Engine(bits, capacity=n, n_tables=m) as e:
+            e.add_codes(codes)
+            e.build_index()
+            for mode in (vc.MODE_MIH_EXACT, vc.MODE_MIH_APPROX):
+                k = 15 if mode == vc.MODE_MIH_EXACT else 5     # (approximate mode stops at 20 k candidates: a cluster holds ~150 items)
+                got, cnt, st = e.search_knn(q, k, mode=mode, with_stats=True)
+                rows[(lines, mode)] = got.copy()
+                for i in range(len(q)):
+                    ores, ost = mo.find(q[i], k, approximate=mode == vc.MODE_MIH_APPROX, stop_mult=min(m, 4) if mode == vc.MODE_MIH_EXACT else 4)
+                    g = got[i, : cnt[i]]
+                    _check_contract(g, ores)
+                    assert (st[i].radius, st[i].n_sub_reads, st[i].n_candidates) == (ost.radius, ost.n_sub_reads, ost.n_distinct), (lines, mode, i)
+                    exp, _ = _canonical_mih(oracle, codes, q[i], m, k, ost.radius, False)
+                    assert np.array_equal(g, exp)
+            for t in range(m):                          # HashIndex -> Image_List views do not depend on the lines
+                key = mo.key(codes[7], t)
+                ids, _, total = e.get_bucket(t, key)
+                assert np.array_equal(ids, mo.bucket(t, key))
+    for mode in (vc.MODE_MIH_EXACT, vc.MODE_MIH_APPROX):
+        assert np.array_equal(rows[("1", mode)], rows[("0", mode)])
