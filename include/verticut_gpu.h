@@ -286,6 +286,12 @@ int vc_sharded_search_knn(vc_sharded* h, const void* queries, uint32_t nq, uint3
 int vc_sharded_search_knn_dev(vc_sharded* h, const void* d_queries, uint32_t nq, uint32_t k, uint32_t mode,
                               uint64_t* d_out, uint32_t* d_counts, vc_query_stats* d_stats, void* stream);
 int vc_sharded_root_device(const vc_sharded* h, int* device);
+/* All items within full Hamming distance <= radius of each query over all shards; arguments, result layout and
+ * VC_ERR_CAPACITY behaviour as vc_search_radius (host buffers).  Every shard searches its id range, the shards' results of a
+ * query are brought together and ordered by the radius search's own segment sort on the root device.
+ * replaces: search_R_neighbors on every rank + gather_vectors + the master-side dedup (search_worker.cc:177-199,222-264). */
+int vc_sharded_search_radius(vc_sharded* h, const void* queries, uint32_t nq, uint32_t radius, uint32_t mode,
+                             uint64_t* out, uint64_t out_cap, uint64_t* out_offsets);
 /* borrow shard g's engine (bucket views, timing, files); its id range is [*first_id, *first_id + *n_ids) */
 int vc_sharded_shard(vc_sharded* h, uint32_t shard, vc_engine** e, uint64_t* first_id, uint64_t* n_ids);
 

@@ -309,3 +309,30 @@ def test_driver_with_sharded_store(vc, oracle, tmp_path):
     assert p.returncode == 0, p.stderr
     pairs = [(int(a), int(b)) for a, b in re.findall(r"^(\d+) : (\d+)$", p.stdout, flags=re.M)]
     assert (4321, 0) in pairs and sorted(d for _, d in pairs) == [int(x >> SH) for x in oracle.linear_knn(codes, codes[4321], k)]
+
+
+@pytest.mark.parametrize("bits,m,shards", [(64, 2, 3), (64, 4, 4), (128, 4, 2)])
+def test_radius_search_over_shards(vc, oracle, bits, m, shards):
+    """vc_sharded_search_radius: search_R_neighbors on every rank + gather_vectors + the master's dedup
+    (search_worker.cc:177-199,222-264) as per-shard radius searches whose per-query results are brought together and ordered
+    on the device: equal to numpy brute force over the union and to one engine, through MIH and through the scan, with an
+    empty trailing shard, a query without neighbours, and an output buffer that is too small at first."""
+    n, radius = 30_000, 9
+    rng = np.random.default_rng(bits + m)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=40, max_flips=6)
+    q = np.concatenate([_queries(codes, rng, 7, 4), rng.integers(0, 256, size=(1, bits // 8), dtype=np.uint8)])
+    with vc.ShardedEngine(bits, capacity=n + 5000, n_shards=shards, n_tables=m, devices=[0], id_base=3) as s, \
+            vc.Engine(bits, capacity=n, n_tables=m, id_base=3) as one:
+        s.add_codes(codes)
+        s.build_index()
+        one.add_codes(codes)
+        one.build_index()
+        for mode in (vc.MODE_MIH_EXACT, vc.MODE_LINEAR):
+            got = s.search_radius(q, radius, mode=mode, cap_per_query=1)      # too small at first: the wrapper repeats with the reported size
+            ref = one.search_radius(q, radius, mode=mode)
+            for i in range(len(q)):
+                d = oracle.np_distances(codes, q[i])
+                ids = np.nonzero(d <= radius)[0]
+                exp = np.sort(oracle.pack(d[ids], ids.astype(np.uint64) + np.uint64(3)))
+                assert np.array_equal(got[i], exp) and np.array_equal(ref[i], exp)
+        assert len(got[-1]) == 0 or bits == 64                               # (a uniform 128-bit query has no neighbour within 9)

@@ -742,6 +742,9 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 #ifndef MQ_LAZY_BINOM
 #define MQ_LAZY_BINOM 1
 #endif
+#ifndef MQ_FAST_OWNER
+#define MQ_FAST_OWNER 1
+#endif
 #ifndef MQ_PERSISTENT
 #define MQ_PERSISTENT 0     // 1: a residency wave of blocks draws queries from a ticket (r04: +3 % against one block per query in the same
 #endif                      // binary, but the loop around the body costs ~20 spilled VGPRs at the 128-register limit: -8 % net) -- off
@@ -1232,7 +1235,22 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       for (uint32_t g = 0; g < MQ_EPT; ++g) {
         bool emit = live[g];
         uint64_t packed = 0;
-        if (live[g]) {
+        if (live[g] && MQ_FAST_OWNER && s == 32 && m == 2u * W) {
+          // the reference's native shape -- 32-bit substrings, every table one half of a code word -- unrolled: the substring
+          // distances are the popcounts of the 2 W dwords of x ^ q, no field extraction, no loop over a run-time table count
+          const uint32_t t = meta[g] & 0xFFu, dt = meta[g] >> 8;
+          uint32_t dist = 0;
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const uint64_t xq = x[g][j] ^ qw[j];
+            const uint32_t d0 = __popc((uint32_t)xq), d1 = __popc((uint32_t)(xq >> 32));
+            dist += d0 + d1;
+            // owner rule: reported by the first table holding the minimum substring distance
+            if (((uint32_t)(2 * j) != t && (d0 < dt || (d0 == dt && (uint32_t)(2 * j) < t))) ||
+                ((uint32_t)(2 * j + 1) != t && (d1 < dt || (d1 == dt && (uint32_t)(2 * j + 1) < t)))) emit = false;
+          }
+          packed = vc_pack(dist, p.id_base + local[g]);
+        } else if (live[g]) {
           const uint32_t t = meta[g] & 0xFFu, dt = meta[g] >> 8;
           uint32_t dist = 0;
           for (uint32_t tt = 0; tt < m; ++tt) {
@@ -2214,6 +2232,16 @@ __global__ void __launch_bounds__(1024) vc_radius_offsets_kernel(const uint32_t*
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// per-query result segments (ring[q * cap ..], count[q] entries each, cap a power of two) -> ascending per query at out[offs[q] ..]
+// (vc_sharded_search_radius: the shards' concatenated results of a query are ordered by the same kernel the radius search uses)
+hipError_t vc_launch_sort_compact_segments(uint64_t* d_ring, uint32_t cap, const uint32_t* d_count, const uint64_t* d_offs,
+                                           uint64_t* d_out, uint64_t out_cap, uint32_t nq, hipStream_t s) {
+  if (nq == 0) return hipSuccess;
+  hipLaunchKernelGGL(vc_sort_compact_segments_kernel, dim3(nq), dim3(1024), 0, s, d_ring, cap, d_count, (const uint32_t*)nullptr, d_offs,
+                     d_out, out_cap);
+  return hipGetLastError();
+}
+
 hipError_t vc_launch_gather_queries(const uint64_t* d_q, const uint32_t* d_list, uint32_t n, uint32_t W, uint64_t* d_out, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(mih_gather_queries_kernel, dim3((n * W + 255) / 256), dim3(256), 0, s, d_q, d_list, n, W, d_out);

@@ -41,6 +41,8 @@ struct VcMihScanFallback {
   uint32_t n_cu = 0;
 };
 // kernels of that switch (vc_mih.hip), launched by the engine between its select and recover launches
+hipError_t vc_launch_sort_compact_segments(uint64_t* d_ring, uint32_t cap, const uint32_t* d_count, const uint64_t* d_offs,
+                                           uint64_t* d_out, uint64_t out_cap, uint32_t nq, hipStream_t s);
 hipError_t vc_launch_gather_queries(const uint64_t* d_q, const uint32_t* d_list, uint32_t n, uint32_t W, uint64_t* d_out, hipStream_t s);
 struct VcMihReplayArgs {
   const uint64_t* lin_ring;   // [gq][lin_cap] candidate rings of the scan (complete: every item at or below the k-th distance)

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "vc_internal.hpp"
+#include "vc_mih.hpp"
 
 namespace {
 
@@ -557,6 +558,71 @@ int vc_sharded_search_knn(vc_sharded* h, const void* queries, uint32_t nq, uint3
     if (counts) counts[i] = cnt[i];
     if (stats) stats[i].n_results = cnt[i];
   }
+  return VC_OK;
+}
+
+// All items within `radius` of every query over all shards (search_R_neighbors per rank + gather_vectors + the master's dedup,
+// search_worker.cc:177-199,222-264: every shard searches its id range, the per-query results of the shards are brought together and
+// ordered).  Shard by shard through the shards' host API (a shard's radius search waits for its own total anyway); the
+// concatenated segments are ordered ON THE DEVICE by the radius search's own segment sort, one block per query.
+int vc_sharded_search_radius(vc_sharded* h, const void* queries, uint32_t nq, uint32_t radius, uint32_t mode, uint64_t* out,
+                             uint64_t out_cap, uint64_t* out_offsets) {
+  if (!h || !queries || !out_offsets || nq == 0 || (mode != VC_MODE_LINEAR && mode != VC_MODE_MIH_EXACT) || (!out && out_cap))
+    return VC_ERR_INVALID;
+  std::vector<std::vector<uint64_t>> res(h->G), offs(h->G, std::vector<uint64_t>((size_t)nq + 1, 0));
+  for (uint32_t g = 0; g < h->G; ++g) {
+    if (shard_size(h, g) == 0) continue;
+    uint64_t cap = (uint64_t)nq * 64;
+    for (int attempt = 0;; ++attempt) {
+      res[g].resize(std::max<uint64_t>(cap, 1));
+      const int rc = vc_search_radius(h->eng[g], queries, nq, radius, mode, res[g].data(), cap, offs[g].data());
+      if (rc == VC_OK) break;
+      if (rc != VC_ERR_CAPACITY || attempt) return sfail(h, rc, "shard %u: %s", g, vc_last_error(h->eng[g]));
+      cap = offs[g][nq];   // the needed size came back in the offsets
+    }
+  }
+  // per-query totals -> output offsets; the largest query sizes the segment ring (a power of two, as the sort wants it)
+  std::vector<uint32_t> count(nq);
+  uint64_t total = 0, mx = 0;
+  for (uint32_t q = 0; q < nq; ++q) {
+    uint64_t c = 0;
+    for (uint32_t g = 0; g < h->G; ++g) c += offs[g][q + 1] - offs[g][q];
+    out_offsets[q] = total;
+    total += c;
+    mx = std::max(mx, c);
+    if (c > 0xFFFFFFFFull) return sfail(h, VC_ERR_CAPACITY, "radius search: a query has more than 2^32 neighbours");
+    count[q] = (uint32_t)c;
+  }
+  out_offsets[nq] = total;
+  if (total > out_cap) return sfail(h, VC_ERR_CAPACITY, "radius search: output buffer too small (needed counts are in out_offsets)");
+  if (total == 0) return VC_OK;
+  uint64_t cap2 = 2;
+  while (cap2 < mx) cap2 <<= 1;
+  if (cap2 > 0x80000000ull || (uint64_t)nq * cap2 * 8 > (64ull << 30)) return sfail(h, VC_ERR_CAPACITY, "radius search: result segments too large to order on the device");
+  std::vector<uint64_t> ring((size_t)nq * cap2);
+  for (uint32_t q = 0; q < nq; ++q) {      // shard after shard = ascending id ranges; the distances interleave: ordered below
+    uint64_t* dst = ring.data() + (size_t)q * cap2;
+    for (uint32_t g = 0; g < h->G; ++g)
+      dst = std::copy(res[g].begin() + offs[g][q], res[g].begin() + offs[g][q + 1], dst);
+  }
+  hipStream_t S = h->root_stream;
+  VS_HIP(h, hipSetDevice(h->root));
+  uint64_t *d_ring = nullptr, *d_offs = nullptr, *d_out = nullptr;
+  uint32_t* d_count = nullptr;
+  auto cleanup = [&]() { (void)hipFree(d_ring); (void)hipFree(d_offs); (void)hipFree(d_out); (void)hipFree(d_count); };
+#define VR_HIP(call) do { hipError_t _r = (call); if (_r != hipSuccess) { cleanup(); return sfail(h, _r == hipErrorOutOfMemory ? VC_ERR_NOMEM : VC_ERR_HIP, "%s: %s", #call, hipGetErrorString(_r)); } } while (0)
+  VR_HIP(hipMalloc((void**)&d_ring, ring.size() * 8));
+  VR_HIP(hipMalloc((void**)&d_offs, ((size_t)nq + 1) * 8));
+  VR_HIP(hipMalloc((void**)&d_out, total * 8));
+  VR_HIP(hipMalloc((void**)&d_count, (size_t)nq * 4));
+  VR_HIP(hipMemcpyAsync(d_ring, ring.data(), ring.size() * 8, hipMemcpyHostToDevice, S));
+  VR_HIP(hipMemcpyAsync(d_offs, out_offsets, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, S));
+  VR_HIP(hipMemcpyAsync(d_count, count.data(), (size_t)nq * 4, hipMemcpyHostToDevice, S));
+  VR_HIP(vc_launch_sort_compact_segments(d_ring, (uint32_t)cap2, d_count, d_offs, d_out, total, nq, S));
+  VR_HIP(hipMemcpyAsync(out, d_out, total * 8, hipMemcpyDeviceToHost, S));
+  VR_HIP(hipStreamSynchronize(S));
+#undef VR_HIP
+  cleanup();
   return VC_OK;
 }
 

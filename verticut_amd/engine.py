@@ -30,7 +30,7 @@ EXPORTS = [
     "vc_search_radius_dev", "vc_read_bitmap_file", "vc_save_index", "vc_load_index",
     "vc_sharded_create", "vc_sharded_destroy", "vc_sharded_last_error", "vc_sharded_exchange", "vc_sharded_add_codes",
     "vc_sharded_add_synthetic", "vc_sharded_size", "vc_sharded_build_index", "vc_sharded_get_code", "vc_sharded_get_bucket",
-    "vc_sharded_search_knn", "vc_sharded_shard", "vc_sharded_search_knn_dev", "vc_sharded_root_device", "vc_search_knn_dev_stats",
+    "vc_sharded_search_knn", "vc_sharded_shard", "vc_sharded_search_knn_dev", "vc_sharded_root_device", "vc_search_knn_dev_stats", "vc_sharded_search_radius",
 ]
 MAX_SHARDS = 16
 EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL = 0, 1, 2
@@ -138,6 +138,7 @@ def load_library():
     L.vc_sharded_shard.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.vc_sharded_search_knn_dev.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp, vp]
     L.vc_sharded_root_device.argtypes = [vp, C.POINTER(C.c_int)]
+    L.vc_sharded_search_radius.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp]
     for name in EXPORTS:
         if getattr(L, name).restype is not C.c_char_p:
             getattr(L, name).restype = C.c_int
@@ -443,6 +444,23 @@ class ShardedEngine:
     def search_knn_dev(self, d_queries, nq, k, d_out, d_counts=None, d_stats=None, mode=MODE_LINEAR, stream=None):
         """vc_sharded_search_knn_dev: raw device addresses on the root device; results valid in `stream` order"""
         self._check(self._L.vc_sharded_search_knn_dev(self._h, d_queries, nq, k, mode, d_out, d_counts, d_stats, stream))
+
+    def search_radius(self, queries, radius, mode=MODE_LINEAR, cap_per_query=64):
+        """vc_sharded_search_radius: list of ascending packed arrays, one per query"""
+        q = np.ascontiguousarray(queries, dtype=np.uint8)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        offs = np.zeros(nq + 1, dtype=np.uint64)
+        cap = nq * cap_per_query
+        for _ in range(2):
+            out = np.empty(max(cap, 1), dtype=np.uint64)
+            rc = self._check(self._L.vc_sharded_search_radius(self._h, _p(q), nq, radius, mode, _p(out), cap, _p(offs)),
+                             ok=(VC_OK, VC_ERR_CAPACITY))
+            if rc == VC_OK:
+                return [out[int(offs[i]):int(offs[i + 1])].copy() for i in range(nq)]
+            cap = int(offs[nq])
+        raise VcError(VC_ERR_CAPACITY, "radius search output does not fit")
 
     def search_knn(self, queries, k, mode=MODE_LINEAR, order=ORDER_ASCENDING, with_stats=False):
         q = np.ascontiguousarray(queries, dtype=np.uint8)
