@@ -1077,7 +1077,10 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     const uint32_t fill = s_ncand;
     if (fill <= MQ_BLK) {
       // the usual case (k + ties survive the final threshold): order by counting -- entry i goes to slot #{j : a[j] < a[i]},
-      // packed values are distinct -- fill broadcast LDS reads and two barriers instead of a 36-stage network
+      // packed values are distinct -- fill broadcast LDS reads and two barriers instead of a 36-stage network.
+      // (r04: spreading the count over all four waves -- MQ_BLK / P threads per entry, partial ranks met in LDS -- is 5.7 % SLOWER
+      // at 1e8, 13.15 vs 13.94 M queries/s: the kernel is bound by the instructions the CU issues in total, and waves that idle
+      // here leave their issue slots to the other blocks of the CU.)
       const uint64_t v = tid < fill ? s_buf[tid] : VC_PACK_INF;
       uint32_t rank = 0;
       for (uint32_t j = 0; j < fill; ++j) rank += s_buf[j] < v;
