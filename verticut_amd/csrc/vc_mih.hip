@@ -742,6 +742,9 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 #ifndef MQ_LAZY_BINOM
 #define MQ_LAZY_BINOM 1
 #endif
+#ifndef MQ_BMW
+#define MQ_BMW 256u                      // words of the drain's entry -> bucket bitmap: drains of up to 8 192 entries use it (one per thread)
+#endif
 #ifndef MQ_FAST_OWNER
 #define MQ_FAST_OWNER 1
 #endif
@@ -909,6 +912,8 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   __shared__ uint32_t s_nh, s_ncand, s_seenc[MQ_MAX_GROUP], s_hits0c[MQ_MAX_GROUP], s_dk, s_wsum[MQ_BLK / VC_WAVE < 4 ? 4 : MQ_BLK / VC_WAVE];   // (s_wsum doubles as the 4 class counters of mq_select_exact)
   __shared__ uint32_t s_segstart[28], s_segh[27], s_segmask[27], s_segr[27], s_nseg;
   __shared__ uint64_t s_thresh;
+  // entry -> bucket map of a drain: bit e set iff a bucket of the hit list starts at entry e, + the set bits before every word
+  __shared__ uint32_t s_bm[MQ_BMW + 1], s_bmpre[MQ_BMW + 1];
 
   __shared__ unsigned long long s_t_entry;   // dev (VC_MIH_PHASES): thread 0's clock at entry -- in LDS, not in a register pair that lives to the end
   __shared__ unsigned long long s_ph_last;
@@ -1101,6 +1106,10 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     __syncthreads();
     tick(2);
     const uint32_t H = min(s_nh, MQ_HMAX);
+    if (MQ_BMW) {                       // (published by the barrier in front of the prefix sums' second half)
+      if (tid < MQ_BMW) s_bm[tid] = 0;
+      if (tid == 0) s_bm[MQ_BMW] = 0;
+    }
     if (LINES && s == 32) {
       // directory lines: occupancy, first entry position, rank and the buckets' extents sit in the ONE sector the scan just
       // read (four 16-byte loads that hit L2); only a line whose buckets fit neither encoding goes on to offsets[]
@@ -1168,7 +1177,10 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 #pragma unroll
     for (uint32_t i = 0; i < MQ_HMAX / MQ_BLK; ++i) {
       const uint32_t idx = tid * (MQ_HMAX / MQ_BLK) + i;
-      if (idx < H) s_pref[idx] = excl;
+      if (idx < H) {
+        s_pref[idx] = excl;
+        if (MQ_BMW && excl < MQ_BMW * 32u) atomicOr(&s_bm[excl >> 5], 1u << (excl & 31u));   // (buckets of the list hold >= 1 entry: distinct starts)
+      }
       excl += lv[i];
     }
     if (tid == 0) s_pref[H] = total;
@@ -1176,6 +1188,25 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
     if (tid == 0) {
       w_hits += H;
       w_entries += total;
+    }
+    // Which bucket does entry e belong to?  Four binary searches in the prefix array per thread and round were the largest
+    // single item of a verified entry's instructions AND a chain of ~7 dependent LDS reads each (r04).  A drain of up to
+    // 32 * MQ_BMW entries marks every bucket's first entry in a bitmap and keeps the set bits before every word: the bucket of
+    // e is then two independent LDS reads and a popcount.
+    // (r04, same box: exact top-100 + 2 % at 1e9 -- 1 714 entries per query --, + 0.5 % at 1e8, approximate mode equal; the
+    // radius search, whose buckets hold one entry each, loses 1.5 % to the map's two barriers and keeps its searches)
+    const bool fastmap = MQ_BMW && knn && total <= MQ_BMW * 32u;     // (block-uniform)
+    if (fastmap) {
+      const uint32_t c = tid < MQ_BMW ? __popc(s_bm[tid]) : 0u;
+      uint32_t wt;
+      uint32_t ex = vc_wave_excl_scan(c, wt);
+      if (lane == 0) s_wsum[wave] = wt;
+      __syncthreads();
+#pragma unroll
+      for (uint32_t w = 0; w < MQ_BLK / VC_WAVE; ++w)
+        if (w < wave) ex += s_wsum[w];
+      if (tid < MQ_BMW) s_bmpre[tid] = ex;
+      __syncthreads();
     }
     tick(3);
 
@@ -1208,9 +1239,14 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
         live[g] = e < total;
         const uint32_t ec = live[g] ? e : 0;
         uint32_t lo = 0, hi = H;               // largest b with s_pref[b] <= e
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_pref[mid] <= ec) lo = mid; else hi = mid;
+        if (fastmap) {
+          const uint32_t wi = ec >> 5;
+          lo = s_bmpre[wi] + __popc(s_bm[wi] & (0xFFFFFFFFu >> (31u - (ec & 31u)))) - 1u;   // bucket starts at or before e, minus one
+        } else {
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_pref[mid] <= ec) lo = mid; else hi = mid;
+          }
         }
         meta[g] = s_meta[lo];
         const VcTableView& tv = s_tv[meta[g] & 0xFFu];
