@@ -696,7 +696,10 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 // round instead of one per shell.  A pass gives every thread MQ_GPT_KNN granules (6: shell 2's 1 304 granules of four
 // tables are one pass).  A query that is not finished after shell r_last (the shells beyond cost > 10^5 probes) writes
 // its state to the slot arrays and joins the `heavy` list, which the multi-block kernels above continue from shell
-// r_last + 1.  The kernel sits at the 128-VGPR limit of its 4 waves per SIMD (tests/test_build_cpu.py guards it):
+// r_last + 1.  Round 4: with directory lines (VcTableView::lines, template parameter LINES) a granule is the first 16 bytes of
+// its key range's 64-byte line and a hit's bucket look-up reads the rest of the SAME sector; k-NN drains map entries to buckets
+// through a bitmap of bucket starts instead of binary searches; the owner rule is unrolled for 32-bit substrings; wave scans run
+// on DPP (vc_common.hpp).  The kernel sits at the 128-VGPR limit of its 4 waves per SIMD (tests/test_build_cpu.py guards it):
 // result / state pointers are read from the kernel-argument segment where they are used (cold()), per-query counters
 // live in LDS, and the rare buffer paths (mq_compact, mq_select_exact) are functions of their own.
 // =============================================================================================================
