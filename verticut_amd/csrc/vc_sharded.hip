@@ -598,7 +598,8 @@ int vc_sharded_search_radius(vc_sharded* h, const void* queries, uint32_t nq, ui
   if (total == 0) return VC_OK;
   uint64_t cap2 = 2;
   while (cap2 < mx) cap2 <<= 1;
-  if (cap2 > 0x80000000ull || (uint64_t)nq * cap2 * 8 > (64ull << 30)) return sfail(h, VC_ERR_CAPACITY, "radius search: result segments too large to order on the device");
+  if (cap2 > 0x80000000ull || (uint64_t)nq * cap2 * 8 > (4ull << 30))   // (the padded segments are assembled in host memory first)
+    return sfail(h, VC_ERR_CAPACITY, "radius search: result segments too large (a query with %llu neighbours x %u queries): search fewer queries per call", (unsigned long long)mx, nq);
   std::vector<uint64_t> ring((size_t)nq * cap2);
   for (uint32_t q = 0; q < nq; ++q) {      // shard after shard = ascending id ranges; the distances interleave: ordered below
     uint64_t* dst = ring.data() + (size_t)q * cap2;
