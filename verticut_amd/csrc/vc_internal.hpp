@@ -31,6 +31,7 @@ struct VcKnobs {
   int mih_lines = -1;                         // VC_MIH_LINES: directory lines of the 32-bit tables (VcTableView::lines): -1 auto, 0 / 1
   int mih_persistent = 1;                     // VC_MIH_PERSISTENT=0: one block per query instead of a residency wave of blocks that draw queries
   int mih_approx_wide = 0;                    // VC_MIH_APPROX_WIDE=1: approximate k-NN on the 512-bit-granule instantiation of the query kernel
+  int mih_order = -1;                         // VC_MIH_ORDER: longest-first launch order of mih_query_kernel (mih_order_kernel): -1 auto (with the directory lines), 0 / 1
   int mih_group = 0;                          // VC_MIH_GROUP=1..3: shells sharing the query kernel's first pass (0 = adaptive)
   uint32_t recover_spin_limit = 0;            // VC_RECOVER_SPIN_LIMIT: bound of the recovery grid barrier's spin (0 = default, ~3 s)
   uint32_t recover_test_fail = 0;             // VC_RECOVER_TEST_FAIL=N (tests): the first N recover launches wait for a block that never comes
