@@ -668,3 +668,34 @@ def test_directory_lines_every_encoding(vc, oracle, monkeypatch, bits, m):
                 assert np.array_equal(ids, mo.bucket(t, key))
     for mode in (vc.MODE_MIH_EXACT, vc.MODE_MIH_APPROX):
         assert np.array_equal(rows[("1", mode)], rows[("0", mode)])
+
+
+@pytest.mark.parametrize("bits,m", [(128, 4), (64, 4)])
+def test_launch_order_does_not_change_results(vc, oracle, monkeypatch, bits, m):
+    """mih_order_kernel (batches of >= two residency waves of blocks: the query kernel's blocks take the queries in ascending
+    order of their shell-0 bucket sizes, longest radius loops first): rows, counts and every statistic of a 4096-query batch are
+    those of the same batch in batch order, and a sample of the queries equals the oracle's SearchWorker::find
+    (search_worker.cc:159-218); with the directory lines (32-bit substrings) and with direct tables (16-bit)."""
+    n, k, nq = 150_000, 20, 4096
+    rng = np.random.default_rng(bits * 7 + m)
+    codes = oracle.gen_codes(n, bits, 34, kind=1, n_centres=500, max_flips=8)
+    q = _near_queries(codes, nq, rng, 3)
+    out = {}
+    for order in ("1", "0"):
+        monkeypatch.setenv("VC_MIH_ORDER", order)
+        monkeypatch.setenv("VC_MIH_LINES", order)
+        with vc.Engine(bits, capacity=n, n_tables=m) as e:
+            e.add_codes(codes)
+            e.build_index()
+            for mode in (vc.MODE_MIH_EXACT, vc.MODE_MIH_APPROX):
+                got, cnt, st = e.search_knn(q, k, mode=mode, with_stats=True)
+                out[(order, mode)] = (got.copy(), cnt.copy(), [(s.radius, s.n_sub_reads, s.n_local_reads, s.n_candidates, s.n_results) for s in st])
+    for mode in (vc.MODE_MIH_EXACT, vc.MODE_MIH_APPROX):
+        a, b = out[("1", mode)], out[("0", mode)]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    got, cnt, st = out[("1", vc.MODE_MIH_EXACT)]
+    for i in rng.choice(nq, size=24, replace=False):
+        ores, ost = mo.find(q[i], k, stop_mult=4)
+        _check_contract(got[i, : cnt[i]], ores)
+        assert st[i][:2] == (ost.radius, ost.n_sub_reads) and st[i][3] == ost.n_distinct
