@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+# MIH workloads: every N-th launch of the MIH kernels is bracketed by timing events (vc_config.timing_sample under VC_FLAG_LEAN_TIMING);
+# an event record is a barrier packet of ~4 us in the stream, two of them per 0.3 ms launch are 3 % of a step
+MIH_TIMING_SAMPLE = int(os.environ.get("VC_BENCH_MIH_TIMING_SAMPLE", "4"))
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a pure copy reaches)
 VALU_PEAK_GOPS = 39321.6  # 256 CUs x 64 lanes x 2.4 GHz 32-bit lane-ops/s; v_xor issues at ~2.3 and
 #                           v_bcnt at ~4.2 cycles per wave64 instruction per SIMD, so the xor+popcount mix tops out near 0.6 of it
@@ -659,7 +662,7 @@ def _extra_c2(args, env, steps=6):
     from verticut_amd import engine as vc
     n, bits, m, Q, radius = 100_000_000, 64, 2, 1024, 8
     rng = np.random.default_rng(args.seed + 2)
-    e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
+    e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING, timing_sample=MIH_TIMING_SAMPLE)
     try:
         e.add_synthetic(n, seed=args.seed)
         e.build_index()
@@ -710,7 +713,7 @@ def _extras_knn_mih(args, env, n, tag, legs, steps=6):
     rng = np.random.default_rng(args.seed + 3)
     out = {}
     t0 = time.perf_counter()
-    e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
+    e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING, timing_sample=MIH_TIMING_SAMPLE)
     try:
         e.add_synthetic(n, seed=args.seed, kind=vc.SYNTH_CLUSTERED, n_centres=max(n // 1000, 1), max_flips=11)
         e.build_index()
@@ -816,7 +819,7 @@ def run_c2(args, env, emit):
     lines = {}
     tables = [int(t) for t in args.tables.split(",")]
     for m in tables:
-        e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
+        e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING, timing_sample=MIH_TIMING_SAMPLE)
         e.add_synthetic(n, seed=args.seed)
         t0 = time.perf_counter()
         e.build_index()
@@ -895,7 +898,7 @@ def run_knn_mih(args, env, emit):
     from verticut_amd import engine as vc
     n, bits, Q, k, m = int(args.n), args.bits, args.queries, args.k, 4
     rng = np.random.default_rng(args.seed + 3)
-    e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING)
+    e = vc.Engine(bits, capacity=n, n_tables=m, flags=vc.FLAG_LEAN_TIMING, timing_sample=MIH_TIMING_SAMPLE)
     e.add_synthetic(n, seed=args.seed, kind=vc.SYNTH_CLUSTERED, n_centres=max(n // 1000, 1), max_flips=11)
     e.build_index()
     if args.uniform_queries:

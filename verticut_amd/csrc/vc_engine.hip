@@ -189,6 +189,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
   e->sbits = sbits;
   e->n_cu = (uint32_t)prop.multiProcessorCount;
   read_knobs(&e->knobs);
+  if ((cfg->flags & VC_FLAG_LEAN_TIMING) && cfg->timing_sample > 1) e->knobs.timing_every = cfg->timing_sample;
   e->recover_sabotage = e->knobs.recover_test_fail;
   e->cap = cfg->cand_cap ? cfg->cand_cap : 65536u;
   // queries verified per database pass: 8 keeps the pass on the HBM side of the roofline (bench), larger tiles trade

@@ -32,6 +32,8 @@ struct VcKnobs {
   int mih_persistent = 1;                     // VC_MIH_PERSISTENT=0: one block per query instead of a residency wave of blocks that draw queries
   int mih_approx_wide = 0;                    // VC_MIH_APPROX_WIDE=1: approximate k-NN on the 512-bit-granule instantiation of the query kernel
   int mih_order = -1;                         // VC_MIH_ORDER: longest-first launch order of mih_query_kernel (mih_order_kernel): -1 auto (with the directory lines), 0 / 1
+  uint32_t timing_every = 1;                  // not an environment knob: vc_config.timing_sample under VC_FLAG_LEAN_TIMING (set by vc_create) --
+                                              // the MIH kernels' launches are bracketed by events only every N-th time as well
   int mih_group = 0;                          // VC_MIH_GROUP=1..3: shells sharing the query kernel's first pass (0 = adaptive)
   uint32_t recover_spin_limit = 0;            // VC_RECOVER_SPIN_LIMIT: bound of the recovery grid barrier's spin (0 = default, ~3 s)
   uint32_t recover_test_fail = 0;             // VC_RECOVER_TEST_FAIL=N (tests): the first N recover launches wait for a block that never comes

@@ -1146,6 +1146,10 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   unsigned long long& w_entries = s_stat[4];
   if (tid < 5) s_stat[tid] = 0;   // (a barrier follows before the first use)
   auto ring_row = [&]() { return cold()->st.ring + (uint64_t)slot * cold()->cap; };   // radius mode only (k-NN hand-over goes through st.topk)
+  // (r04: publishing the launch's counters to the host from the block that ends last -- a device-scope fence and a ticket per
+  // block, so that no reduce kernel stands between the query kernel and the polling host -- made the kernel 60 % SLOWER, 0.443
+  // against 0.274 ms per 4096 queries: a device-scope release writes the XCD's L2 back, 4096 times per launch.  The reduce
+  // kernel behind the launch keeps that job.)
   auto put_work = [&]() {
     if (tid == 0) {
       cold()->st.work[slot * 4 + 0] = w_probes;
@@ -2462,6 +2466,7 @@ struct VcMihIndex {
   // measurement (vc_get_timing): event pairs around every mih_query_kernel launch, device totals of its work counters
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
+  uint32_t launch_tick = 0, launches_all = 0;   // every knobs.timing_every-th launch is timed; all are counted
   unsigned long long* d_totals = nullptr;   // probes | non-empty buckets | entries verified | queries
   uint64_t* d_ring = nullptr;               // [MIH_QTILE][cap] candidate rings of the multi-block shells (lazy)
   size_t ring_entries = 0;
@@ -3167,7 +3172,8 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
     if (r != hipSuccess) return r;
   }
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  if (ix->ev_used < 4096) {
+  ++ix->launches_all;
+  if (ix->ev_used < 4096 && ix->launch_tick++ % std::max(ix->knobs.timing_every, 1u) == 0) {
     if (ix->ev_used == ix->ev_pool.size()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) == hipSuccess) {
@@ -3212,7 +3218,8 @@ static hipError_t timed_stream_launch(VcMihIndex* ix, StreamParams sp, uint32_t 
   }
   sp.totals = ix->d_totals;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  if (ix->ev_used < 4096) {
+  ++ix->launches_all;
+  if (ix->ev_used < 4096 && ix->launch_tick++ % std::max(ix->knobs.timing_every, 1u) == 0) {
     if (ix->ev_used == ix->ev_pool.size()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) == hipSuccess) {
@@ -3248,6 +3255,13 @@ void vc_mih_timing(VcMihIndex* ix, float* ms, uint32_t* launches, uint64_t total
     }
   }
   ix->ev_used = 0;
+  // launches that were not bracketed by events (timing_every > 1) are priced at the timed ones' average: the work counters
+  // below cover ALL launches, and the callers divide them by this launch count
+  if (*launches && ix->launches_all > *launches) {
+    *ms = *ms / (float)*launches * (float)ix->launches_all;
+    *launches = ix->launches_all;
+  }
+  ix->launches_all = 0;
   if (ix->d_totals) {
     unsigned long long h[4] = {0, 0, 0, 0};
     if (hipMemcpyAsync(h, ix->d_totals, 32, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemsetAsync(ix->d_totals, 0, 32, s) == hipSuccess &&
