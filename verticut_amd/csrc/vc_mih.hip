@@ -675,21 +675,17 @@ __global__ void __launch_bounds__(256) vc_fill_u32_kernel(uint32_t* p, uint32_t 
 // known beforehand, but how many database items share one of its substrings EXACTLY -- the lengths of its m shell-0 buckets
 // -- predicts it well (the fifth of a batch with the smallest sums holds 81 % of its shell-3 queries, oracle run on 2 M
 // clustered codes): few exact companions = a sparse neighbourhood = a long radius loop.  One thread per query looks its m
-// buckets up and sums their lengths; the block that arrives last puts the queries with fewer than k exact companions in
-// ascending order of that sum at the front of order[] and the others behind them (a plain two-class partition -- front / back
-// cursors, no order inside the classes -- keeps a quarter of the gain: 0.347 vs 0.316 ms per launch at 1e9); the query kernel's
-// blocks read order[] instead of their own index.  Results do not depend on the order.
+// buckets up and sums their lengths; every block of the pre-pass orders its 64 queries by that sum and deals them into order[]
+// round-robin with the other blocks -- sorted up to sampling noise, no exchange between blocks (a plain two-class partition,
+// fewer than k exact companions first and no order inside the classes, keeps only a quarter of the gain: 0.347 vs 0.316 ms per
+// launch at 1e9); the query kernel's blocks read order[] instead of their own index.  Results do not depend on the order.
 // =============================================================================================================
 #define MO_BLK 256u
-#define MO_BINS 1024u
-#define MO_QPT (MIH_QTILE / MO_BLK)       // queries per thread of the ordering block (a launch covers one tile: <= MIH_QTILE queries)
 __global__ void __launch_bounds__(MO_BLK) mih_order_kernel(const VcTableView* __restrict__ tables, const uint64_t* __restrict__ queries,
-                                                           uint32_t W, uint32_t m, uint32_t sbits, uint32_t nq, uint32_t limit,
-                                                           uint32_t* __restrict__ score, uint32_t* __restrict__ order, uint32_t* __restrict__ ticket) {
-  __shared__ uint32_t s_bin[MO_BINS], s_wtot[MO_BLK / VC_WAVE], s_back, s_last, s_sc[MO_BLK];
-  // phase 1: one thread per (query, table) -- nq * m / 256 blocks, so that the look-ups of a 4096-query batch spread over 64 CUs
-  // (with a thread per query they were 16 blocks: 1 000 random sectors per CU)
-  const uint32_t per_block = MO_BLK / m;                       // queries of this block (m divides 256 for m = 1, 2, 4, 8, ...)
+                                                           uint32_t W, uint32_t m, uint32_t sbits, uint32_t nq, uint32_t* __restrict__ order) {
+  __shared__ uint32_t s_sc[MO_BLK];
+  // one thread per (query, table): nq * m / 256 blocks, so that the look-ups of a 4096-query batch spread over 64 CUs
+  const uint32_t per_block = MO_BLK / m;                       // queries of a block
   const uint32_t ql = threadIdx.x / m, t = threadIdx.x - ql * m;
   const uint32_t q = blockIdx.x * per_block + ql;
   const uint32_t smask = sbits == 32 ? 0xFFFFFFFFu : ((1u << sbits) - 1u);
@@ -718,60 +714,23 @@ __global__ void __launch_bounds__(MO_BLK) mih_order_kernel(const VcTableView* __
     if (len) atomicAdd(&s_sc[ql], len);
   }
   __syncthreads();
-  if (threadIdx.x < per_block && blockIdx.x * per_block + threadIdx.x < nq) score[blockIdx.x * per_block + threadIdx.x] = min(s_sc[threadIdx.x], limit);
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
-    s_back = 0;
-  }
-  for (uint32_t i = threadIdx.x; i < MO_BINS; i += MO_BLK) s_bin[i] = 0;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  // ---- the block that arrives last orders the batch: queries with fewer than `limit` (= k) exact companions -- the long radius
-  // loops -- by ascending score at the front (counting sort: their scores spread over the bins), all the others behind them in
-  // any order (one LDS atomic per wave: per-lane atomics on the one bin they would share took 15 us)
-  const uint32_t lane = vc_lane();
-  uint32_t sc[MO_QPT];
-#pragma unroll
-  for (uint32_t i = 0; i < MO_QPT; ++i) {
-    const uint32_t qq = i * MO_BLK + threadIdx.x;
-    sc[i] = qq < nq ? vc_ld_relaxed(score + qq) : 0xFFFFFFFFu;
-    if (sc[i] < limit) atomicAdd(&s_bin[min(sc[i], MO_BINS - 1u)], 1u);
-  }
-  __syncthreads();
-  {   // exclusive scan over the bins (MO_BINS / MO_BLK consecutive bins per thread)
-    uint32_t c[MO_BINS / MO_BLK], mine = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < MO_BINS / MO_BLK; ++i) {
-      c[i] = s_bin[threadIdx.x * (MO_BINS / MO_BLK) + i];
-      mine += c[i];
+  // The block orders ITS queries by ascending score and deals them into the launch order round-robin with the other blocks:
+  // local rank r of block b -> position r * blocks + b.  Every block holds a random sample of the batch, so the dealt sequence
+  // is sorted up to the sampling noise -- with no word exchanged between blocks (a device-scope fence and a ticket per block,
+  // for the block that arrives last to sort the whole batch, made this pre-pass 20 us: a release writes an XCD's L2 back).
+  const uint32_t nb = gridDim.x, last_cnt = nq - (nb - 1u) * per_block;   // queries of the last block (1 .. per_block)
+  const uint32_t mine_n = blockIdx.x + 1u == nb ? last_cnt : per_block;
+  if (threadIdx.x < mine_n) {
+    const uint32_t sc = s_sc[threadIdx.x];
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < mine_n; ++j) {
+      const uint32_t o = s_sc[j];
+      r += o < sc || (o == sc && j < threadIdx.x);
     }
-    uint32_t wt;
-    uint32_t ex = vc_wave_excl_scan(mine, wt);
-    if (lane == 0) s_wtot[threadIdx.x / VC_WAVE] = wt;
-    __syncthreads();
-    for (uint32_t w = 0; w < threadIdx.x / VC_WAVE; ++w) ex += s_wtot[w];
-#pragma unroll
-    for (uint32_t i = 0; i < MO_BINS / MO_BLK; ++i) {
-      s_bin[threadIdx.x * (MO_BINS / MO_BLK) + i] = ex;
-      ex += c[i];
-    }
+    // ranks >= last_cnt do not exist in the last block: the rows of the deal from there on are one short
+    const uint32_t pos = r * nb - (r > last_cnt ? r - last_cnt : 0u) + blockIdx.x;
+    order[pos] = blockIdx.x * per_block + threadIdx.x;
   }
-  __syncthreads();
-#pragma unroll
-  for (uint32_t i = 0; i < MO_QPT; ++i) {
-    const uint32_t qq = i * MO_BLK + threadIdx.x;
-    const bool valid = qq < nq, longq = valid && sc[i] < limit;
-    if (longq) order[atomicAdd(&s_bin[min(sc[i], MO_BINS - 1u)], 1u)] = qq;
-    const uint64_t ms = __ballot(valid && !longq);
-    uint32_t b = 0;
-    if (lane == 0 && ms) b = atomicAdd(&s_back, (uint32_t)__popcll(ms));
-    b = __builtin_amdgcn_readfirstlane(b);
-    if (valid && !longq) order[nq - 1u - (b + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull)))] = qq;
-  }
-  if (threadIdx.x == 0) *ticket = 0;      // ready for the next launch: no memset in front of it
 }
 
 // =============================================================================================================
@@ -3080,8 +3039,8 @@ static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, bool with_ring,
     ix->ring_entries = Q * cap;
   }
   if (!ix->d_lists) {   // 4 slot lists + 4 counters + 4 stop-shell counts (the counters start at zero; the reduce kernel re-zeroes what a launch counted)
-    MIH_CHECK(hipMalloc((void**)&ix->d_lists, (6 * Q + 16) * 4));   // ... + the launch order [Q] and its scores [Q] behind a 16-word counter block
-    MIH_CHECK(hipMemset(ix->d_lists + 4 * Q, 0, 64));                // (word 9: the order kernel's ticket)
+    MIH_CHECK(hipMalloc((void**)&ix->d_lists, (5 * Q + 16) * 4));   // ... + the launch order [Q] behind a 16-word counter block
+    MIH_CHECK(hipMemset(ix->d_lists + 4 * Q, 0, 64));
   }
   uint8_t* b = (uint8_t*)ix->d_tile;
   st->thresh = (uint64_t*)(b + o_thresh);
@@ -3377,16 +3336,14 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
       qp.buf_entries = buf_entries; qp.heavy_list = cur; qp.heavy_ctr = d_ctr + 2;
       qp.out = d_out + (size_t)q0 * k; qp.out_cnt = d_cnt + q0; qp.group = group; qp.radius_hist = d_ctr + 4;
       qp.use_lines = (S == 32 && !ix->h_tables.empty() && ix->h_tables[0].lines) ? 1u : 0u;
-      // (r04, same box: at 1e9 the query kernel 0.364 -> 0.316 ms per 4096 queries; at 1e8 0.271 -> 0.259 ms, which the pre-pass
-      // eats: on by default where the directory lines are, i.e. from 3e8 records)
-      const bool want_order = ix->knobs.mih_order < 0 ? qp.use_lines != 0 : ix->knobs.mih_order != 0;
+      // (r04, same box: the query kernel 0.353 -> 0.319 ms per 4096 queries at 1e9, 0.277 -> 0.269 ms at 1e8, for a pre-pass of
+      // ~3 us; VC_MIH_ORDER=0 switches it off)
+      const bool want_order = ix->knobs.mih_order != 0;
       if (want_order && qt >= 4 * ix->n_cu * 2 && ix->m <= MO_BLK) {   // at least two residency waves of blocks: a launch order matters
-        uint32_t* d_ticket = d_ctr + 9;               // zero at allocation, re-zeroed by the kernel's last block
         uint32_t* d_order = d_ctr + 16;
-        uint32_t* d_score = d_order + MIH_QTILE;
         const uint32_t per_block = MO_BLK / ix->m;
         hipLaunchKernelGGL(mih_order_kernel, dim3((qt + per_block - 1) / per_block), dim3(MO_BLK), 0, s, (const VcTableView*)ix->d_tables,
-                           d_q + (size_t)q0 * ix->W, ix->W, ix->m, S, qt, MO_BINS - 1u, d_score, d_order, d_ticket);
+                           d_q + (size_t)q0 * ix->W, ix->W, ix->m, S, qt, d_order);
         MIH_CHECK(hipGetLastError());
         qp.order = d_order;
       }
