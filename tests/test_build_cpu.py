@@ -53,6 +53,6 @@ def test_shipped_query_kernels_of_the_configs_shapes_have_no_scratch(vc):
     assert len(narrow) == 6
     for k, v in narrow.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
-        assert v["vgpr_count"] <= 128 and v["sgpr_spill_count"] <= 72, (k, v)   # (to VGPR lanes; what must stay zero is scratch and VGPR spills)
+        assert v["vgpr_count"] <= 128 and v["sgpr_spill_count"] <= 64, (k, v)   # (to the lanes of ONE VGPR; scratch and VGPR spills must stay zero)
     stream = {k: v for k, v in vb.kernel_resources(obj).items() if "mih_bucket_stream_kernel" in k}
     assert stream and all(v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 for v in stream.values())

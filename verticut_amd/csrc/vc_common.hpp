@@ -44,15 +44,6 @@ __device__ __forceinline__ uint32_t vc_lane() { return __builtin_amdgcn_mbcnt_hi
 #define VC_DPP_ROW_BCAST15 0x142
 #define VC_DPP_ROW_BCAST31 0x143
 __device__ __forceinline__ uint32_t vc_wave_incl_scan(uint32_t x) {
-#if defined(VC_WAVE_SHFL) && VC_WAVE_SHFL     // dev A/B: the round-3 __shfl ladder
-  const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-#pragma unroll
-  for (int off = 1; off < VC_WAVE; off <<= 1) {
-    uint32_t y = __shfl_up(x, off, VC_WAVE);
-    if (lane >= (uint32_t)off) x += y;
-  }
-  return x;
-#endif
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, VC_DPP_ROW_SHR(1), 0xf, 0xf, false);
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, VC_DPP_ROW_SHR(2), 0xf, 0xf, false);
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, VC_DPP_ROW_SHR(4), 0xf, 0xf, false);

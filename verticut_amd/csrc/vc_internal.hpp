@@ -29,8 +29,6 @@ struct VcKnobs {
                                               // vc_tau_init_kernel launch (measured: the 1024 prologues cost 20 us, the launch 5 -- off)
   int mih_poll = 1;                           // VC_MIH_POLL=0: wait for the query kernel's counters with hipStreamSynchronize instead of polling
   int mih_lines = -1;                         // VC_MIH_LINES: directory lines of the 32-bit tables (VcTableView::lines): -1 auto, 0 / 1
-  int mih_persistent = 1;                     // VC_MIH_PERSISTENT=0: one block per query instead of a residency wave of blocks that draw queries
-  int mih_approx_wide = 0;                    // VC_MIH_APPROX_WIDE=1: approximate k-NN on the 512-bit-granule instantiation of the query kernel
   int mih_order = 1;                          // VC_MIH_ORDER=0: mih_query_kernel's blocks take the queries in batch order (no longest-first pre-pass, mih_order_kernel)
   uint32_t timing_every = 1;                  // not an environment knob: vc_config.timing_sample under VC_FLAG_LEAN_TIMING (set by vc_create) --
                                               // the MIH kernels' launches are bracketed by events only every N-th time as well

@@ -817,9 +817,9 @@ __global__ void __launch_bounds__(MO_BLK) mih_order_kernel(const VcTableView* __
 #ifndef MQ_FAST_OWNER
 #define MQ_FAST_OWNER 1
 #endif
-#ifndef MQ_PERSISTENT
-#define MQ_PERSISTENT 0     // 1: a residency wave of blocks draws queries from a ticket (r04: +3 % against one block per query in the same
-#endif                      // binary, but the loop around the body costs ~20 spilled VGPRs at the 128-register limit: -8 % net) -- off
+// (r04: a persistent form -- one residency wave of blocks drawing queries from a ticket counter, no workgroup launch per query --
+// was built: + 3 % against one block per query inside the same binary, but the loop around the body keeps ~20 more registers
+// alive at the 128-VGPR limit: - 5 % net, and every slot busy only made the blocks live longer.  Removed; profiles/r04_sweeps.md.)
 static __host__ __device__ inline uint32_t mq_hist_bins(uint32_t W) { return (W * 64u + 1u + 7u) & ~7u; }
 
 struct QueryKernelParams {
@@ -842,8 +842,6 @@ struct QueryKernelParams {
   uint32_t* out_cnt;
   unsigned long long* phase_dbg;  // dev (VC_MIH_PHASES): [8] phase times of mih_query_kernel, summed over the launch; [8..13] block lifetimes by stop shell (0..4, handed over), [16..21] their counts, [24] start of the first block, [25..30] latest end by stop shell
   const uint32_t* order;       // k-NN: block b serves query order[b] (longest-first, mih_order_kernel); null = query b
-  uint32_t nq;                 // queries of the launch
-  uint32_t* ticket;            // k-NN: persistent blocks draw their queries here (zero at launch); null = block b serves query b
   uint32_t use_lines;          // k-NN, 32-bit substrings: probe the directory lines (VcTableView::lines) instead of bitmap + blockoff + offsets
   uint32_t group;              // k-NN, 32-bit substrings: shells 0 .. group-1 share the first pass (1 = one shell per pass)
   uint32_t* radius_hist;       // k-NN: [4] queries of the launch by the shell they stopped in (0, 1, 2, later / handed over)
@@ -989,12 +987,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   __shared__ unsigned long long s_ph_last;
   __shared__ uint32_t s_ph_cur;
   __shared__ unsigned long long s_stat[5];
-#if MQ_PERSISTENT
-  __shared__ uint32_t s_slot;
-  uint32_t slot = blockIdx.x;
-#else
   const uint32_t slot = p.order ? p.order[blockIdx.x] : blockIdx.x;   // (block-uniform: a scalar load)
-#endif
   const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
   const uint32_t s = p.sbits, m = p.m;
   const uint32_t smask = s == 32 ? 0xFFFFFFFFu : ((1u << s) - 1u);
@@ -1017,14 +1010,11 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   }
 
   // ---- one query, start to end (a persistent block runs this for every query it draws)
-#if MQ_PERSISTENT
-  auto run_query = [&]() __attribute__((always_inline)) {
-#endif
   if (p.phase_dbg && threadIdx.x == 0) s_t_entry = __builtin_amdgcn_s_memrealtime();
 
   uint64_t qw[W];
 #pragma unroll
-  for (int j = 0; j < W; ++j) qw[j] = (MQ_PERSISTENT ? cold()->queries : p.queries)[(uint64_t)slot * W + j];
+  for (int j = 0; j < W; ++j) qw[j] = p.queries[(uint64_t)slot * W + j];
   auto qkey = [&](uint32_t t) {
     const uint32_t bp = t * s;
     uint32_t v = 0;
@@ -1792,27 +1782,6 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       atomicMax(&p.phase_dbg[30], now);
     }
   }
-#if MQ_PERSISTENT
-  };   // run_query
-#endif
-
-  // Persistent form (k-NN launches): the grid is one residency wave and every block draws queries from a ticket counter until
-  // they are gone -- a workgroup launch per query (LDS allocation, wave start, kernel-argument and table reads) cost the
-  // slots a fifth of their time (r04: the blocks' lifetimes summed to 62 % of slots x kernel time).
-  // (ONE call site: called from two places the body became a function of its own, closure and all in scratch)
-#if MQ_PERSISTENT
-  for (;;) {
-    if (cold()->ticket) {
-      __syncthreads();                    // the previous query's LDS state is dead
-      if (tid == 0) s_slot = atomicAdd(cold()->ticket, 1u);
-      __syncthreads();
-      slot = __builtin_amdgcn_readfirstlane(s_slot);   // (scalar: addresses derived from it stay scalar)
-      if (slot >= cold()->nq) return;
-    }
-    run_query();
-    if (!cold()->ticket) return;
-  }
-#endif
 }
 
 // =============================================================================================================
@@ -3076,28 +3045,12 @@ static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits,
          (size_t)m * sizeof(VcTableView) + 16;                                                   // the tables' views
 }
 
-// grid of a launch: one block per query, or -- persistent form (p.ticket) -- one residency wave of blocks that draw their queries
-template <class K>
-static uint32_t query_grid(K kernel, const QueryKernelParams& p, size_t lds, uint32_t nq, uint32_t n_cu) {
-  if (!p.ticket) return nq;
-  static thread_local struct { const void* fn; size_t lds; int occ; } cache[8] = {};
-  int occ = 0;
-  for (auto& c : cache)
-    if (c.fn == (const void*)kernel && c.lds == lds) occ = c.occ;
-  if (occ == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, (int)MQ_BLK, lds) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 1; }
-    for (auto& c : cache)
-      if (!c.fn) { c.fn = (const void*)kernel; c.lds = lds; c.occ = occ; break; }
-  }
-  return (uint32_t)std::min<uint64_t>(nq, (uint64_t)occ * std::max(n_cu, 1u));
-}
-
-static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s, uint32_t n_cu = 0, bool wide = false) {
+static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s) {
   const size_t lds = query_kernel_lds(p.buf_entries, p.m, p.sbits, W);
-#define MQ_LAUNCH_K(K_) hipLaunchKernelGGL((K_), dim3(query_grid((K_), p, lds, nq, n_cu)), dim3(MQ_BLK), lds, s, p)
+#define MQ_LAUNCH_K(K_) hipLaunchKernelGGL((K_), dim3(nq), dim3(MQ_BLK), lds, s, p)
 #define MQ_LAUNCH(W_)                                                                                           \
   case W_:                                                                                                      \
-    if (p.mode == MQ_MODE_RADIUS || wide) MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_RADIUS, false>));             \
+    if (p.mode == MQ_MODE_RADIUS) MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_RADIUS, false>));                     \
     else if (p.use_lines && MQ_LO_KNN == 7u) MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_KNN, MQ_LO_KNN == 7u>));   \
     else MQ_LAUNCH_K((mih_query_kernel<W_, MQ_LO_KNN, false>));                                                 \
     break;
@@ -3142,10 +3095,9 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
     if (ix->ev_used < ix->ev_pool.size()) ev = &ix->ev_pool[ix->ev_used++];
   }
   if (ev) (void)hipEventRecord(ev->first, s);
-  // approximate k-NN walks deep shells (20 k candidates: mean radius ~4 on the bench data = 10 ^ 5 probes per query), where a
-  // 64-byte granule -- one whole sector, as in the radius search -- takes fewer sectors than 16-byte ones (dev knob VC_MIH_APPROX_WIDE)
-  const bool wide = p.mode == MQ_MODE_APPROX && p.sbits == 32 && ix->knobs.mih_approx_wide;
-  hipError_t r = launch_query_kernel(p, W, nq, s, ix->n_cu, wide);
+  // (approximate k-NN on the 512-bit-granule instantiation -- its deep shells are sector-bound like the radius search's -- measured
+  // 10 % slower than on 128-bit granules, 0.81 vs 0.89 M queries/s: r04_sweeps.md)
+  hipError_t r = launch_query_kernel(p, W, nq, s);
   if (ev) (void)hipEventRecord(ev->second, s);
   if (r != hipSuccess) return r;
   // (k-NN launches: heavy_ctr = the tile's counter block + 2.  Radius search has no counters to publish, and its work
@@ -3347,8 +3299,6 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
         MIH_CHECK(hipGetLastError());
         qp.order = d_order;
       }
-      qp.nq = qt;
-      qp.ticket = (MQ_PERSISTENT && ix->knobs.mih_persistent) ? d_ctr + 3 : nullptr;   // (zero: memset above / re-zeroed by every reduce kernel)
       const auto t_q = std::chrono::steady_clock::now();
       if (!ix->h_ctr_dev) MIH_CHECK(hipMemsetAsync(d_ctr, 0, 32, s));   // (else zeroed at allocation and by every reduce kernel since)
       MIH_CHECK(timed_query_launch(ix, qp, ix->W, qt, s));
