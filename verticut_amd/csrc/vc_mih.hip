@@ -1811,16 +1811,19 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
 #define MS_MAXP 2048u                    // probes of one query (all tables, all shells) held in LDS
 #endif
 
+#define MS_TOT_LINES 256u                 // copies of the launch's work counters, one 128-byte line each
+
 struct StreamParams {
   const uint64_t* queries;               // [nq][W]
   const VcTableView* tables;
   uint64_t* ring;                        // [nq][cap]
   uint32_t* count;                       // [nq]
-  unsigned long long* totals;            // probes | non-empty buckets | entries | -
+  unsigned long long* totals;            // [MS_TOT_LINES][16]: probes | non-empty buckets | entries | queries, summed by vc_mih_timing
   uint64_t n;                            // entries per table (stride of the bucket-order copies)
   uint32_t m, sbits, id_base, flags, cap, radius;
   uint32_t rsub, n_big, small_shells;    // shells 0..rsub for tables 0..n_big-1, shells 0..small_shells-1 for the others
   uint32_t nprobes, split;
+  unsigned long long* trace;             // dev (VC_STREAM_TRACE): per block start | probes looked up | end, 10 ns ticks
 };
 
 template <int W>
@@ -1843,6 +1846,7 @@ __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamPara
     return v;
   };
   if (tid < 2) s_tot[tid] = 0;
+  if (p.trace && tid == 0) p.trace[3ull * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   __syncthreads();
   // ---- this block's probes: j = part, part + split, ...  ->  (shell r, table t, index in the shell) -> bucket
   uint32_t nloc = 0;
@@ -1879,12 +1883,17 @@ __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamPara
   if (hits) atomicAdd(&s_tot[0], hits);
   if (entries) atomicAdd(&s_tot[1], entries);
   __syncthreads();
+  // (r04: these three atomics used to go to ONE 32-byte record, 5 121 of them per 1024-query launch -- same-address atomics retire
+  // one every ~9 ns chip-wide, and wave 0 of every block waited for its own before it could consume its first bucket:
+  // 0.44 -> 0.40 ms per launch without them, profiles/r04_stream_trace.txt.  Now MS_TOT_LINES records, one per 128-byte line.)
   if (tid == 0 && p.totals) {
-    atomicAdd(&p.totals[1], s_tot[0]);
-    atomicAdd(&p.totals[2], s_tot[1]);
-    if (part == 0) atomicAdd(&p.totals[0], (unsigned long long)p.nprobes);
-    if (blockIdx.x == 0) atomicAdd(&p.totals[3], (unsigned long long)(gridDim.x / p.split));   // queries of the launch
+    unsigned long long* const tot = p.totals + (size_t)(blockIdx.x % MS_TOT_LINES) * 16;
+    atomicAdd(&tot[1], s_tot[0]);
+    atomicAdd(&tot[2], s_tot[1]);
+    if (part == 0) atomicAdd(&tot[0], (unsigned long long)p.nprobes);
+    if (blockIdx.x == 0) atomicAdd(&tot[3], (unsigned long long)(gridDim.x / p.split));   // queries of the launch
   }
+  if (p.trace && tid == 0) p.trace[3ull * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   // ---- every wave streams whole buckets
   uint64_t* const ring = p.ring + (uint64_t)slot * p.cap;
   // Results are staged per wave: a group of hits used to cost the wave a returning global atomic (ring space) and a gather
@@ -1943,7 +1952,7 @@ __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamPara
   // (r04: the wave's buckets as ONE stream of 128-entry segments -- no half-empty second round per 1 526-entry bucket, 4 % idle
   // lane slots instead of 25 % -- was built and is 23 % SLOWER, 0.563 against 0.435 ms per launch on one box: the idle lanes'
   // clamped loads hit the cache and cost next to nothing, while a cursor that crosses bucket boundaries puts LDS reads and
-  // scalar bookkeeping between the loads of a round.  What bounds the kernel is the run length: profiles/r04_stream_runs.txt)
+  // scalar bookkeeping between the loads of a round.)
   for (uint32_t b = wave; b < nloc; b += blockDim.x / VC_WAVE) {
     const uint32_t off = s_off[b], len = s_len[b], t = s_meta[b] & 0xFFu, dt = s_meta[b] >> 8;
     if (len == 0) continue;
@@ -1991,6 +2000,10 @@ __global__ void __launch_bounds__(256) mih_bucket_stream_kernel(const StreamPara
     }
   }
   if (fill) flush();
+  if (p.trace) {
+    __syncthreads();
+    if (tid == 0) p.trace[3ull * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 
@@ -2396,6 +2409,7 @@ struct VcMihIndex {
   size_t ev_used = 0;
   uint32_t launch_tick = 0, launches_all = 0;   // every knobs.timing_every-th launch is timed; all are counted
   unsigned long long* d_totals = nullptr;   // probes | non-empty buckets | entries verified | queries
+  unsigned long long* d_stotals = nullptr;  // the stream kernel's share of the same, [MS_TOT_LINES][16]
   uint64_t* d_ring = nullptr;               // [MIH_QTILE][cap] candidate rings of the multi-block shells (lazy)
   size_t ring_entries = 0;
   size_t lds_per_block = 65536;             // hipDeviceProp.sharedMemPerBlock of the index's device
@@ -2444,6 +2458,7 @@ void vc_mih_free(VcMihIndex* ix) {
   if (ix->h_ctr) (void)hipHostFree(ix->h_ctr);
   for (auto& pr : ix->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   (void)hipFree(ix->d_totals);
+  (void)hipFree(ix->d_stotals);
   (void)hipFree(ix->d_ring);
   delete ix;
 }
@@ -3121,13 +3136,39 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
 }
 
 // launch + measurement of mih_bucket_stream_kernel (same records as the query kernels: vc_timing.mih_*)
+// blocks of mih_bucket_stream_kernel<W> the chip holds at once
+static uint32_t stream_resident_blocks(uint32_t W, uint32_t n_cu) {
+  static uint32_t per_cu[9] = {};
+  if (W > 8) return n_cu;
+  if (!per_cu[W]) {
+    int b = 0;
+    hipError_t r = hipErrorInvalidValue;
+    switch (W) {
+      case 1: r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mih_bucket_stream_kernel<1>, 256, 0); break;
+      case 2: r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mih_bucket_stream_kernel<2>, 256, 0); break;
+      case 4: r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mih_bucket_stream_kernel<4>, 256, 0); break;
+      case 8: r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mih_bucket_stream_kernel<8>, 256, 0); break;
+    }
+    if (r != hipSuccess) (void)hipGetLastError();
+    per_cu[W] = (r == hipSuccess && b > 0) ? (uint32_t)b : 2u;
+  }
+  return per_cu[W] * n_cu;
+}
+
 static hipError_t timed_stream_launch(VcMihIndex* ix, StreamParams sp, uint32_t W, uint32_t nq, hipStream_t s) {
-  if (!ix->d_totals) {
-    hipError_t r = hipMalloc((void**)&ix->d_totals, 32);
-    if (r == hipSuccess) r = hipMemsetAsync(ix->d_totals, 0, 32, s);
+  if (!ix->d_stotals) {
+    hipError_t r = hipMalloc((void**)&ix->d_stotals, MS_TOT_LINES * 128);
+    if (r == hipSuccess) r = hipMemsetAsync(ix->d_stotals, 0, MS_TOT_LINES * 128, s);
     if (r != hipSuccess) return r;
   }
-  sp.totals = ix->d_totals;
+  sp.totals = ix->d_stotals;
+  static const bool dev_trace = getenv("VC_STREAM_TRACE") != nullptr;   // dev: per-block start / look-up / end times on stderr
+  const uint32_t nblocks = nq * sp.split;
+  unsigned long long* d_trace = nullptr;
+  if (dev_trace && hipMalloc((void**)&d_trace, (size_t)nblocks * 24) == hipSuccess) {
+    (void)hipMemsetAsync(d_trace, 0, (size_t)nblocks * 24, s);
+    sp.trace = d_trace;
+  }
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   ++ix->launches_all;
   if (ix->ev_used < 4096 && ix->launch_tick++ % std::max(ix->knobs.timing_every, 1u) == 0) {
@@ -3150,6 +3191,38 @@ static hipError_t timed_stream_launch(VcMihIndex* ix, StreamParams sp, uint32_t 
   }
   hipError_t r = hipGetLastError();
   if (ev) (void)hipEventRecord(ev->second, s);
+  if (d_trace) {   // dev: when do the blocks start, finish their probe look-up and end?  (us after the first block's start)
+    std::vector<unsigned long long> h((size_t)nblocks * 3);
+    if (hipMemcpyAsync(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+      unsigned long long t0 = ~0ull;
+      for (uint32_t b = 0; b < nblocks; ++b) t0 = std::min(t0, h[3 * b]);
+      std::vector<double> st, lk, en, life;
+      for (uint32_t b = 0; b < nblocks; ++b) {
+        st.push_back((h[3 * b] - t0) * 0.01);
+        lk.push_back((h[3 * b + 1] - h[3 * b]) * 0.01);
+        en.push_back((h[3 * b + 2] - t0) * 0.01);
+        life.push_back((h[3 * b + 2] - h[3 * b]) * 0.01);
+      }
+      auto pr = [&](const char* name, std::vector<double> v) {
+        std::sort(v.begin(), v.end());
+        auto q = [&](double f) { return v[(size_t)(f * (v.size() - 1))]; };
+        fprintf(stderr, "[stream trace] %-10s min/p10/p50/p90/p99/max us: %.1f %.1f %.1f %.1f %.1f %.1f\n", name, q(0), q(.1), q(.5), q(.9), q(.99), q(1));
+      };
+      fprintf(stderr, "[stream trace] %u blocks (%u queries x %u parts)\n", nblocks, nq, sp.split);
+      pr("start", st); pr("look-up", lk); pr("end", en); pr("lifetime", life);
+      // blocks alive over time (20 samples of the launch's span)
+      const double span = *std::max_element(en.begin(), en.end());
+      fprintf(stderr, "[stream trace] blocks alive at 5%%..100%% of %.1f us:", span);
+      for (int i = 1; i <= 20; ++i) {
+        const double t = span * i / 20.0 - 1e-9;
+        uint32_t alive = 0;
+        for (uint32_t b = 0; b < nblocks; ++b) alive += st[b] <= t && en[b] > t;
+        fprintf(stderr, " %u", alive);
+      }
+      fprintf(stderr, "\n");
+    }
+    (void)hipFree(d_trace);
+  }
   return r;
 }
 
@@ -3178,6 +3251,13 @@ void vc_mih_timing(VcMihIndex* ix, float* ms, uint32_t* launches, uint64_t total
     if (hipMemcpyAsync(h, ix->d_totals, 32, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemsetAsync(ix->d_totals, 0, 32, s) == hipSuccess &&
         hipStreamSynchronize(s) == hipSuccess)
       for (int i = 0; i < 4; ++i) totals[i] = h[i];
+  }
+  if (ix->d_stotals) {
+    std::vector<unsigned long long> h((size_t)MS_TOT_LINES * 16);
+    if (hipMemcpyAsync(h.data(), ix->d_stotals, MS_TOT_LINES * 128, hipMemcpyDeviceToHost, s) == hipSuccess &&
+        hipMemsetAsync(ix->d_stotals, 0, MS_TOT_LINES * 128, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
+      for (uint32_t l = 0; l < MS_TOT_LINES; ++l)
+        for (int i = 0; i < 4; ++i) totals[i] += h[(size_t)l * 16 + i];
   }
 }
 
@@ -3568,7 +3648,10 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
           sp.m = ix->m; sp.sbits = ix->sbits; sp.id_base = id_base; sp.flags = ix->flags; sp.cap = cap; sp.radius = radius;
           sp.rsub = rsub; sp.n_big = n_big; sp.small_shells = small_shells; sp.nprobes = stream_probes;
           // enough blocks to fill the chip when the batch is small: a query's probe list is dealt out to `split` blocks
-          sp.split = std::max(1u, std::min(std::min(stream_probes, 64u), (8 * n_cu + qt - 1) / qt));
+          // (r04: 8 x n_cu blocks were 2048 for a tile of 1024 queries, 1.6 residency waves of 1280 -- the last fifth of the launch
+          // ran on 768 blocks and fewer; one wave of blocks that are all resident ends 1.3 % earlier, more and smaller blocks pay
+          // for their look-ups: 0.396 / 0.391 / 0.406 ms at 8 / 4 / 16 blocks per CU, profiles/r04_stream_trace.txt)
+          sp.split = std::max(1u, std::min(std::min(stream_probes, 64u), stream_resident_blocks(W, n_cu) / qt));
           R_CHECK(timed_stream_launch(ix, sp, W, qt, s));
         } else {
           uint32_t* list = ix->d_lists;
