@@ -703,6 +703,7 @@ def _extras_knn_mih(args, env, n, tag, legs, steps=6):
     """SearchWorker::find through MIH on `n` clustered 128-bit codes (n/1000 centres, <= 11 flips; m = 4 x 32 bit): ONE engine
     (data + index built once), one short measurement per leg:
       exact    MIH_EXACT, 4096 near-duplicate queries per call            (search_worker.cc:159-218)
+      exact16k the same in calls of 16384 queries (one launch: the launch's tail is paid once)
       uniform  MIH_EXACT, 64 uniform random queries per call: the radius loop would walk to shell ~8; answered through the
                cost-model switch by the verify kernel with the stop rule replayed
       approx   MIH_APPROX, 4096 near-duplicate queries per call           (search_worker.cc:93-157)
@@ -721,12 +722,15 @@ def _extras_knn_mih(args, env, n, tag, legs, steps=6):
         t_setup = time.perf_counter() - t0
         st = torch.cuda.current_stream().cuda_stream
         for leg in legs:
-            name = "knn_%s_%s" % ({"exact": "mih", "uniform": "uniform", "approx": "approx"}[leg], tag)
+            name = "knn_%s_%s" % ({"exact": "mih", "exact16k": "mih", "uniform": "uniform", "approx": "approx"}[leg], tag) + ("_q16k" if leg == "exact16k" else "")
             try:
-                Q = 64 if leg == "uniform" else 4096
+                Q = {"uniform": 64, "exact16k": 16384}.get(leg, 4096)
                 mode = vc.MODE_MIH_APPROX if leg == "approx" else vc.MODE_MIH_EXACT
                 if leg == "uniform":
                     host_q = [rng.integers(0, 256, size=(Q, bits // 8), dtype=np.uint8) for _ in range(2)]
+                elif leg == "exact16k":     # one set, dealt two ways (a D2H code read per query: 16 384 of them take a second)
+                    h0 = _near_queries(e, n, Q, bits, 4, rng)
+                    host_q = [h0, np.ascontiguousarray(h0[::-1])]
                 else:
                     host_q = [_near_queries(e, n, Q, bits, 4, rng) for _ in range(2)]
                 dq = [torch.from_numpy(h).to(env.device) for h in host_q]
@@ -760,6 +764,8 @@ def _extras_knn_mih(args, env, n, tag, legs, steps=6):
                 times = step_times_ms(env, one, nst)
                 e.timing()
                 r = {"workload": {"exact": "exact top-100 through MIH (MIH_EXACT), 128-bit, %.3g clustered codes, m=4, 4096 near-duplicate queries per call",
+                                  "exact16k": "exact top-100 through MIH (MIH_EXACT), 128-bit, %.3g clustered codes, m=4, 16384 near-duplicate queries per call "
+                                              "(one mih_query_kernel launch: a launch's tail -- it ends with its longest query -- is paid once per 16384 queries, not per 4096)",
                                   "uniform": "MIH_EXACT with 64 UNIFORM random queries per call over %.3g clustered codes: shells 0..3 in the query kernel, then the "
                                              "cost-model switch to the verify kernel, stop rule replayed",
                                   "approx": "approximate top-100 through MIH (MIH_APPROX, stop at 20k candidates), 128-bit, %.3g clustered codes, m=4, 4096 queries per call"}[leg] % n,
@@ -790,7 +796,7 @@ def run_extras(args, env):
             out[name] = fn()
         except Exception as ex:   # an extra never takes the headline down with it; the failure is reported in its place
             out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-    for n, tag, legs in ((100_000_000, "1e8", ("exact", "approx")), (1_000_000_000, "1e9", ("exact", "uniform"))):
+    for n, tag, legs in ((100_000_000, "1e8", ("exact", "exact16k", "approx")), (1_000_000_000, "1e9", ("exact", "exact16k", "uniform"))):
         try:
             out.update(_extras_knn_mih(args, env, n, tag, legs))
         except Exception as ex:

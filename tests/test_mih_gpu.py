@@ -699,3 +699,37 @@ def test_launch_order_does_not_change_results(vc, oracle, monkeypatch, bits, m):
         ores, ost = mo.find(q[i], k, stop_mult=4)
         _check_contract(got[i, : cnt[i]], ores)
         assert st[i][:2] == (ost.radius, ost.n_sub_reads) and st[i][3] == ost.n_distinct
+
+
+@pytest.mark.parametrize("bits,m,nq", [(128, 4, 10_000), (128, 4, 20_000), (64, 4, 5_000)])
+def test_launch_size_does_not_change_results(vc, oracle, monkeypatch, bits, m, nq):
+    """A call's queries run in as few mih_query_kernel launches as VC_MIH_QTILE allows (default 16 384 per launch, equally filled:
+    20 000 queries = 2 x 10 048 slots; the per-slot state grows with the batch): rows, counts and every statistic equal those of
+    the same call in launches of 4 096, including the queries handed over to the multi-block shells and the far queries that the
+    cost-model switch sends to the verify kernel; a sample equals the oracle's SearchWorker::find (search_worker.cc:159-218)."""
+    n, k = 120_000, 20
+    rng = np.random.default_rng(bits + nq)
+    codes = oracle.gen_codes(n, bits, 35, kind=1, n_centres=400, max_flips=8)
+    q = _near_queries(codes, nq, rng, 3)
+    q[::997] = rng.integers(0, 256, size=q[::997].shape, dtype=np.uint8)      # a few far queries: hand-over / switch
+    out = {}
+    for tile in ("0", "4096"):
+        monkeypatch.setenv("VC_MIH_QTILE", tile)
+        with vc.Engine(bits, capacity=n, n_tables=m) as e:
+            e.add_codes(codes)
+            e.build_index()
+            for mode in (vc.MODE_MIH_EXACT, vc.MODE_MIH_APPROX):
+                got, cnt, st = e.search_knn(q, k, mode=mode, with_stats=True)
+                out[(tile, mode)] = (got.copy(), cnt.copy(), [(s.radius, s.n_sub_reads, s.n_local_reads, s.n_candidates, s.n_results) for s in st])
+            small, scnt = e.search_knn(q[:100], k, mode=vc.MODE_MIH_EXACT)    # a small batch after a big one: the state is laid out anew
+            assert np.array_equal(small, out[(tile, vc.MODE_MIH_EXACT)][0][:100]) and np.array_equal(scnt, out[(tile, vc.MODE_MIH_EXACT)][1][:100])
+    for mode in (vc.MODE_MIH_EXACT, vc.MODE_MIH_APPROX):
+        a, b = out[("0", mode)], out[("4096", mode)]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    mo = oracle.MihOracle(codes, m, key_mode=1)
+    got, cnt, st = out[("0", vc.MODE_MIH_EXACT)]
+    near = [i for i in rng.choice(nq, size=40, replace=False) if i % 997][:16]
+    for i in near:
+        ores, ost = mo.find(q[i], k, stop_mult=4)
+        _check_contract(got[i, : cnt[i]], ores)
+        assert st[i][:2] == (ost.radius, ost.n_sub_reads) and st[i][3] == ost.n_distinct

@@ -124,6 +124,7 @@ static void read_knobs(VcKnobs* k) {
   if (const char* v = getenv("VC_MIH_POLL")) k->mih_poll = atoi(v);
   if (const char* v = getenv("VC_MIH_LINES")) k->mih_lines = atoi(v);
   if (const char* v = getenv("VC_MIH_ORDER")) k->mih_order = atoi(v);
+  if (const char* v = getenv("VC_MIH_QTILE")) k->mih_qtile = atoi(v);
   if (const char* v = getenv("VC_RECOVER_SPIN_LIMIT")) k->recover_spin_limit = (uint32_t)strtoul(v, nullptr, 10);
   if (const char* v = getenv("VC_RECOVER_TEST_FAIL")) k->recover_test_fail = (uint32_t)strtoul(v, nullptr, 10);
 }

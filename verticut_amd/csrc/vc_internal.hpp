@@ -29,6 +29,7 @@ struct VcKnobs {
                                               // vc_tau_init_kernel launch (measured: the 1024 prologues cost 20 us, the launch 5 -- off)
   int mih_poll = 1;                           // VC_MIH_POLL=0: wait for the query kernel's counters with hipStreamSynchronize instead of polling
   int mih_lines = -1;                         // VC_MIH_LINES: directory lines of the 32-bit tables (VcTableView::lines): -1 auto, 0 / 1
+  int mih_qtile = 0;                          // VC_MIH_QTILE: most queries of one mih_query_kernel launch (0 = default 16384; 4096 .. 65536)
   int mih_order = 1;                          // VC_MIH_ORDER=0: mih_query_kernel's blocks take the queries in batch order (no longest-first pre-pass, mih_order_kernel)
   uint32_t timing_every = 1;                  // not an environment knob: vc_config.timing_sample under VC_FLAG_LEAN_TIMING (set by vc_create) --
                                               // the MIH kernels' launches are bracketed by events only every N-th time as well

@@ -34,7 +34,14 @@
 #define MIH_PPT 4                       // probes per thread
 #define MIH_EPT 4u                      // bucket entries per thread and round in the verify phase
 #define MIH_PCH (MIH_BLK * MIH_PPT)     // probes per block pass
-#define MIH_QTILE 4096u                 // queries resident per search tile (one block each in mih_query_kernel)
+// Queries of one k-NN launch (one block each in mih_query_kernel).  A launch ends when its LONGEST query does, so every launch
+// carries a fixed tail: the exact top-100 kernel takes 90 us + 41.7 ns per query at 1e8 records (60 us + 56 ns at 1e9) --
+// 14.6 M queries/s in launches of 4096, 18.2 M of 8192, 20.4 M of 16384 (11.9 / 14.6 / 16.5 M at 1e9; profiles/r04_sweeps.md, 9).
+// A call's queries are dealt to as few launches as VC_MIH_QTILE (default MIH_QTILE_MAX) allows; the per-slot state grows with
+// the largest batch seen (>= MIH_QTILE_MIN slots).
+#define MIH_QTILE_MIN 4096u
+#define MIH_QTILE_MAX 16384u
+#define MIH_QTILE_LIMIT 65536u           // VC_MIH_QTILE is clamped to MIH_QTILE_MIN .. this
 #define MIH_RADIUS_TILE 4096u            // queries per tile of the radius search (vc_radius_offsets_kernel: four per thread)
 #define MIH_APPROX_FACTOR 20u           // search_worker.h:14
 
@@ -2400,7 +2407,7 @@ struct VcMihIndex {
   uint32_t tile_k = 0, tile_cap = 0;
   void* d_tile = nullptr;
   size_t tile_bytes = 0;
-  uint32_t* d_lists = nullptr;   // 3 * MIH_QTILE + 4 counters
+  uint32_t* d_lists = nullptr;   // 4 slot lists of qtile_max entries + counters + the launch order
   uint32_t* h_ctr = nullptr;     // pinned: the counters the host reads back after every launch sequence
   uint32_t* h_ctr_dev = nullptr; // its device-side alias (mapped): the query kernel's counters are stored there directly
   uint32_t ctr_seq = 0;          // sequence number of the last counter publication (h_ctr[8] when it has landed)
@@ -2410,7 +2417,7 @@ struct VcMihIndex {
   uint32_t launch_tick = 0, launches_all = 0;   // every knobs.timing_every-th launch is timed; all are counted
   unsigned long long* d_totals = nullptr;   // probes | non-empty buckets | entries verified | queries
   unsigned long long* d_stotals = nullptr;  // the stream kernel's share of the same, [MS_TOT_LINES][16]
-  uint64_t* d_ring = nullptr;               // [MIH_QTILE][cap] candidate rings of the multi-block shells (lazy)
+  uint64_t* d_ring = nullptr;               // [slots of the tile][cap] candidate rings of the multi-block shells (lazy)
   size_t ring_entries = 0;
   size_t lds_per_block = 65536;             // hipDeviceProp.sharedMemPerBlock of the index's device
   uint32_t group_hint = 2;                  // shells grouped into the query kernel's first pass (adapts to where queries stop)
@@ -3001,8 +3008,13 @@ int vc_mih_load(VcMihIndex** out, const char* path, const uint64_t* d_cols, uint
 // ---- search -------------------------------------------------------------------------------------------
 // per-slot state of a search tile.  The candidate rings ([slot][cap], 2 GB at the default cap) are used only by the
 // multi-block shells and are allocated the first time a query gets there (with_ring).
-static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, bool with_ring, MihState* st, std::string* err) {
-  const size_t Q = MIH_QTILE;
+static uint32_t qtile_max(const VcMihIndex* ix) {
+  const int v = ix->knobs.mih_qtile;
+  return v > 0 ? std::min(std::max((uint32_t)v, MIH_QTILE_MIN), MIH_QTILE_LIMIT) : MIH_QTILE_MAX;
+}
+// `slots`: queries of the call's largest launch (the state is laid out for exactly that many, so one call passes one value)
+static int ensure_tile(VcMihIndex* ix, uint32_t slots, uint32_t k, uint32_t cap, bool with_ring, MihState* st, std::string* err) {
+  const size_t Q = std::max(slots, MIH_QTILE_MIN);
   size_t bytes = 0;
   auto take = [&](size_t b) { size_t o = bytes; bytes += (b + 255) & ~(size_t)255; return o; };
   const size_t o_thresh = take(Q * 8), o_count = take(Q * 4), o_prev = take(Q * 4),
@@ -3023,8 +3035,9 @@ static int ensure_tile(VcMihIndex* ix, uint32_t k, uint32_t cap, bool with_ring,
     ix->ring_entries = Q * cap;
   }
   if (!ix->d_lists) {   // 4 slot lists + 4 counters + 4 stop-shell counts (the counters start at zero; the reduce kernel re-zeroes what a launch counted)
-    MIH_CHECK(hipMalloc((void**)&ix->d_lists, (5 * Q + 16) * 4));   // ... + the launch order [Q] behind a 16-word counter block
-    MIH_CHECK(hipMemset(ix->d_lists + 4 * Q, 0, 64));
+    const size_t QM = qtile_max(ix);   // (laid out for the largest tile once: the counter block must not move between calls)
+    MIH_CHECK(hipMalloc((void**)&ix->d_lists, (5 * QM + 16) * 4));   // ... + the launch order [QM] behind a 16-word counter block
+    MIH_CHECK(hipMemset(ix->d_lists + 4 * QM, 0, 64));
   }
   uint8_t* b = (uint8_t*)ix->d_tile;
   st->thresh = (uint64_t*)(b + o_thresh);
@@ -3333,9 +3346,13 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   // device (k = 3073..7168 asks for ~82 KB); otherwise every shell runs through the multi-block kernels
   const bool inblock = ix->knobs.mih_host_loop == 0 && buf_entries <= 8192 && ix->m <= 64 &&
                        query_kernel_lds(buf_entries, ix->m, S, ix->W) <= ix->lds_per_block;
-  if ((rc = ensure_tile(ix, k, cap, !inblock, &st, err))) return rc;
-  uint32_t* lists[4] = {ix->d_lists, ix->d_lists + MIH_QTILE, ix->d_lists + 2 * MIH_QTILE, ix->d_lists + 3 * MIH_QTILE};
-  uint32_t* d_ctr = ix->d_lists + 4 * MIH_QTILE;
+  // the call's queries in as few launches as the tile limit allows, equally filled (20 000 queries = 2 x 10 000, not 16 384 + 3 616)
+  const uint32_t QM = qtile_max(ix);
+  const uint32_t n_tiles = std::max(1u, (nq + QM - 1) / QM);
+  const uint32_t tile = std::max(64u, std::min(QM, (((nq + n_tiles - 1) / n_tiles) + 63u) & ~63u));
+  if ((rc = ensure_tile(ix, tile, k, cap, !inblock, &st, err))) return rc;
+  uint32_t* lists[4] = {ix->d_lists, ix->d_lists + QM, ix->d_lists + 2 * QM, ix->d_lists + 3 * QM};
+  uint32_t* d_ctr = ix->d_lists + 4 * QM;
   const double avg_bucket = (double)ix->n / (S >= 32 ? 4294967296.0 : (double)(1ull << S));
   // One block per query: a small batch leaves most of the chip idle while a few blocks walk a big shell, so the probe
   // budget per query shrinks with the batch (a lone query runs shells 0..2 in its block -- 2 116 probes at m = 4 -- and
@@ -3356,8 +3373,8 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   uint32_t group = ix->knobs.mih_group > 0 ? (uint32_t)ix->knobs.mih_group : ix->group_hint;
   group = std::max(1u, std::min(group, std::min(3u, r_last + 1)));
 
-  for (uint32_t q0 = 0; q0 < nq; q0 += MIH_QTILE) {
-    const uint32_t qt = std::min(MIH_QTILE, nq - q0);
+  for (uint32_t q0 = 0; q0 < nq; q0 += tile) {
+    const uint32_t qt = std::min(tile, nq - q0);
     uint32_t *cur = lists[0], *nxt = lists[1], *redo = lists[2];
     uint32_t n_cur = qt, r_start = 0, n_heavy = qt;
     if (inblock) {
@@ -3400,7 +3417,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_q).count());
       if (n_heavy) {
         MIH_CHECK(hipMemcpyAsync(lists[3], cur, (size_t)n_heavy * 4, hipMemcpyDeviceToDevice, s));
-        if ((rc = ensure_tile(ix, k, cap, true, &st, err))) return rc;   // the rings exist from the first hand-over on
+        if ((rc = ensure_tile(ix, tile, k, cap, true, &st, err))) return rc;   // the rings exist from the first hand-over on
         hipLaunchKernelGGL(mih_seed_ring_kernel, dim3(n_heavy), dim3(256), 0, s, st, (const uint32_t*)cur, k, cap);
         MIH_CHECK(hipGetLastError());
         if (fb && fb->fn && switch_ok) {
@@ -3626,7 +3643,7 @@ static int radius_search_device(VcMihIndex* ix, bool use_mih, const uint64_t* d_
       const uint32_t* sorted_flag = nullptr;
       const unsigned long long* work = nullptr;   // mih_query_kernel's per-query work counters of this tile
       if (use_mih) {
-        if ((rc = ensure_tile(ix, 1, 1, false, &st, err))) return rc;
+        if ((rc = ensure_tile(ix, MIH_RADIUS_TILE, 1, 1, false, &st, err))) return rc;
         st.ring = wk->d_ring;   // radius search keeps every neighbour: the big ring instead of the tile's
         st.count = d_count;
         st.topn = d_sorted;
