@@ -14,7 +14,7 @@ cd $R
 step() { echo "== $*" | tee -a $OUT/log.txt; }
 step bench c3; python bench.py --steps 30 --warmup 5 > $OUT/bench_c3.json 2> $OUT/bench_c3.err || { tail -20 $OUT/bench_c3.err; exit 1; }
 cut -c1-400 $OUT/bench_c3.json
-for w in "c1 --workload c1" "sharded1dev --workload sharded1dev" "knn_mih_1e9 --workload knn_mih --db-size 1e9" "knn_mih --workload knn_mih" "knn_approx --workload knn_mih --approximate" "c2 --workload c2" "knn_uniform --workload knn_mih --uniform-queries --queries 64" "knn_uniform_1e9 --workload knn_mih --uniform-queries --queries 64 --db-size 1e9"; do set -- $w; name=$1; shift
+for w in "c1 --workload c1" "sharded1dev --workload sharded1dev" "knn_mih_1e9 --workload knn_mih --db-size 1e9" "knn_mih --workload knn_mih" "knn_mih_q16k --workload knn_mih --queries 16384 --steps 8" "knn_mih_1e9_q16k --workload knn_mih --db-size 1e9 --queries 16384 --steps 8" "knn_approx --workload knn_mih --approximate" "c2 --workload c2" "knn_uniform --workload knn_mih --uniform-queries --queries 64" "knn_uniform_1e9 --workload knn_mih --uniform-queries --queries 64 --db-size 1e9"; do set -- $w; name=$1; shift
   step bench $name; python bench.py "$@" --cpu-seconds 8 --no-traffic > $OUT/bench_$name.json 2> $OUT/bench_$name.err || { tail -20 $OUT/bench_$name.err; exit 1; }
   cut -c1-300 $OUT/bench_$name.json
 done
@@ -27,7 +27,7 @@ step pmc c3 write; rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv
 for w in "knn_mih_1e9 --workload knn_mih --db-size 1e9" "knn_mih --workload knn_mih" "knn_approx --workload knn_mih --approximate" "c2 --workload c2" "sharded1dev --workload sharded1dev"; do set -- $w; name=$1; shift
   step stats $name; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 $R/bench.py "$@" --cpu-seconds 0 --no-check --no-traffic > $OUT/stats_$name.log 2>&1 || { tail -5 $OUT/stats_$name.log; exit 1; }
 done
-for w in "knn_mih_1e9 --workload knn_mih --db-size 1e9" "knn_mih --workload knn_mih" "knn_approx --workload knn_mih --approximate" "c2m4 --workload c2 --tables 4" "c2m2 --workload c2 --tables 2"; do set -- $w; name=$1; shift
+for w in "knn_mih_1e9 --workload knn_mih --db-size 1e9" "knn_mih --workload knn_mih" "knn_mih_q16k --workload knn_mih --queries 16384" "knn_approx --workload knn_mih --approximate" "c2m4 --workload c2 --tables 4" "c2m2 --workload c2 --tables 2"; do set -- $w; name=$1; shift
   step pmc $name fetch; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_${name}_fetch -- python3 $R/bench.py "$@" --steps 4 --warmup 2 --cpu-seconds 0 --no-check --no-traffic > $OUT/pmc_${name}_fetch.log 2>&1 || { tail -5 $OUT/pmc_${name}_fetch.log; exit 1; }
   step pmc $name tcc; rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_${name}_tcc -- python3 $R/bench.py "$@" --steps 4 --warmup 2 --cpu-seconds 0 --no-check --no-traffic > $OUT/pmc_${name}_tcc.log 2>&1 || { tail -5 $OUT/pmc_${name}_tcc.log; exit 1; }
 done

@@ -76,10 +76,10 @@ print("c3: %.1f q/s, scan %.4f ms, frac %.3f, traffic/alg %.4f (bench line: %s);
     {k: (round(v.get("value", 0)), round(v.get("frac") or 0, 3)) for k, v in b.get("extras", {}).items()}))
 
 # ---- the other workloads
-for w in ("c1", "sharded1dev", "knn_mih_1e9", "knn_mih", "knn_approx", "c2", "knn_uniform", "knn_uniform_1e9"):
+for w in ("c1", "sharded1dev", "knn_mih_1e9", "knn_mih", "knn_mih_q16k", "knn_mih_1e9_q16k", "knn_approx", "c2", "knn_uniform", "knn_uniform_1e9"):
     bw = bench(w)
     json.dump(bw, open("%s_bench_%s.json" % (prefix, w), "w"))
-    if w not in ("knn_uniform", "knn_uniform_1e9", "c1"):
+    if w not in ("knn_uniform", "knn_uniform_1e9", "c1", "knn_mih_q16k", "knn_mih_1e9_q16k"):
         stats(w, "%s_%s_kernel_stats.csv" % (prefix, w))
     print("%s: %.1f q/s, %s %.4f ms/launch, cpu %.1f q/s on %d threads" % (
         w, bw["value"], bw["roofline"]["kernel"], bw["roofline"].get("avg_launch_ms") or float("nan"),
@@ -87,6 +87,7 @@ for w in ("c1", "sharded1dev", "knn_mih_1e9", "knn_mih", "knn_approx", "c2", "kn
 
 # ---- MIH counters: effective traffic of the probing kernels next to the algorithmic bytes
 for w, bname, kernel in (("knn_mih_1e9", "knn_mih_1e9", "mih_query_kernel"), ("knn_mih", "knn_mih", "mih_query_kernel"),
+                         ("knn_mih_q16k", "knn_mih_q16k", "mih_query_kernel"),
                          ("knn_approx", "knn_approx", "mih_query_kernel"),
                          ("c2m2", "c2", "mih_query_kernel"), ("c2m4", "c2", "mih_bucket_stream_kernel")):
     bw = bench(bname)
