@@ -4,7 +4,8 @@
 #   at 1e9) + rocprofv3 --kernel-trace --stats of the same command + separate --pmc passes (FETCH_SIZE | WRITE_SIZE) for the
 #   verify kernel; the other workloads' lines (c1, sharded1dev, knn_mih at 1e9 / 1e8, approximate, c2, uniform), kernel stats and
 #   FETCH_SIZE | TCC passes of the MIH kernels; a 125 M-code shard timeline.
-# usage: tools/profile_round4.sh <tag>   -> gpurun_out/<tag>/ ; tools/summarize_round4.py turns it into profiles/r04_*
+# usage: tools/profile_round4.sh <tag>   -> gpurun_out/<tag>/ ; tools/summarize_round4.py runs at the end (on the box) and leaves what
+# goes to profiles/ in gpurun_out/<tag>/summary/r04_*; the raw passes are deleted
 set -o pipefail
 TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
@@ -33,6 +34,10 @@ for w in "knn_mih_1e9 --workload knn_mih --db-size 1e9" "knn_mih --workload knn_
 done
 step shard timeline; $R/tools/timeline_shard.sh $TAG/shard 8 > $OUT/shard_timeline.log 2>&1 || { tail -5 $OUT/shard_timeline.log; exit 1; }
 tail -30 $OUT/shard_timeline.log
-find $OUT -name "*_kernel_trace.csv" -size +5M -delete
 find $OUT -name "*.db" -delete
+# summarised on the box: gpurun copies at most 64 MiB back, the raw passes of this script are more
+mkdir -p $OUT/summary
+python3 $R/tools/summarize_round4.py $OUT $OUT/summary/r04 > $OUT/summary/summary.log 2>&1 || { tail -5 $OUT/summary/summary.log; exit 1; }
+cat $OUT/summary/summary.log
+rm -rf $OUT/stats_* $OUT/pmc_* $OUT/shard/trace
 du -sh $OUT
