@@ -779,6 +779,29 @@ def _extras_knn_mih(args, env, n, tag, legs, steps=6):
                         r["mih_kernel_frac"] = r["frac"]
                         r["frac"] = r["verify_kernel"]["frac"]
                         r["kernel"] = "vc_scan_kernel (dominant: %.3f of %.3f ms per step) behind mih_query_kernel" % (tm.scan_ms / nst, elapsed / nst * 1e3)
+                if leg in ("exact", "exact16k"):
+                    # what a SearchWorker::find caller sees: the same calls through vc_search_knn with HOST pointers --
+                    # H2D of the queries, D2H of Q x k x 8 bytes of rows into pageable memory, inside the timed region
+                    hp = {"rows_bytes_per_call": Q * k * 8,
+                          "what": "vc_search_knn: H2D of the queries + D2H of the rows inside the timed region, synchronous calls; result buffers "
+                                  "allocated once -- ordinary (pageable) numpy arrays, and page-locked ones (one DMA, no staging)"}
+                    for kind in ("pageable", "pinned"):
+                        if kind == "pinned":
+                            h_out = torch.empty((Q, k), dtype=torch.int64).pin_memory().numpy().view(np.uint64)
+                            h_cnt = torch.empty((Q,), dtype=torch.int32).pin_memory().numpy().view(np.uint32)
+                            h_q = [torch.from_numpy(h).pin_memory().numpy() for h in host_q]
+                        else:
+                            h_out, h_cnt, h_q = np.zeros((Q, k), dtype=np.uint64), np.zeros(Q, dtype=np.uint32), host_q
+                        e.search_knn(h_q[0], k, mode=mode, out=h_out, counts=h_cnt)
+                        th = time.perf_counter()
+                        for i in range(4):
+                            e.search_knn(h_q[i % 2], k, mode=mode, out=h_out, counts=h_cnt)
+                        dth = time.perf_counter() - th
+                        ok = ok and bool(np.array_equal(h_out[:16] >> np.uint64(32), e.search_knn(h_q[3 % 2][:16], k, mode=vc.MODE_LINEAR)[0] >> np.uint64(32)))
+                        hp[kind] = {"value": Q * 4 / dth, "unit": "queries/s", "ms_per_call": dth / 4 * 1e3}
+                    e.timing()
+                    r["host_pointers"] = hp
+                    r["results_check"] = "ok" if ok else "FAILED"
                 if leg == "exact":
                     r["setup_s"] = t_setup        # data generation + index build (+ {id, code} records)
                 out[name] = r

@@ -269,3 +269,41 @@ def test_merge_of_sorted_lists_equals_numpy(vc, n_lists, nq, k):
         exp = allv[:k]
         assert np.array_equal(got[q], exp), (q, n_lists, k)
         assert c[q] == int((exp != INF).sum())
+
+
+@pytest.mark.parametrize("nq,k", [(6, 100), (700, 100), (3000, 100), (1500, 400)])
+def test_host_pointer_calls_pageable_and_page_locked(vc, oracle, nq, k):
+    """vc_search_knn's three ways home for the rows (SearchWorker::find's caller holds host memory, search_worker.cc:65-89): one
+    pinned staging buffer (<= 512 KB), two pinned chunks with the DMA of one overlapping the host copy of the other (pageable
+    destination), one DMA (page-locked destination).  All equal the device-resident call and the oracle's linear scan."""
+    import torch
+    n, bits = 40_000, 128
+    rng = np.random.default_rng(nq + k)
+    codes = oracle.gen_codes(n, bits, 5, kind=1, n_centres=200, max_flips=8)
+    q = codes[rng.integers(0, n, size=nq)].copy()
+    q[:, 0] ^= rng.integers(0, 4, size=nq, dtype=np.uint8)
+    with vc.Engine(bits, capacity=n, n_tables=4) as e:
+        e.add_codes(codes)
+        e.build_index()
+        for mode in (vc.MODE_LINEAR, vc.MODE_MIH_EXACT):
+            ref, rcnt = e.search_knn(q, k, mode=mode)                                   # fresh pageable arrays
+            out = np.zeros((nq, k), dtype=np.uint64)
+            cnt = np.zeros(nq, dtype=np.uint32)
+            e.search_knn(q, k, mode=mode, out=out, counts=cnt)                          # caller's pageable arrays
+            assert np.array_equal(out, ref) and np.array_equal(cnt, rcnt)
+            pout = torch.zeros((nq, k), dtype=torch.int64).pin_memory().numpy().view(np.uint64)
+            pcnt = torch.zeros((nq,), dtype=torch.int32).pin_memory().numpy().view(np.uint32)
+            pq = torch.from_numpy(q).pin_memory().numpy()
+            e.search_knn(pq, k, mode=mode, out=pout, counts=pcnt)                       # page-locked: straight DMA
+            assert np.array_equal(pout, ref) and np.array_equal(pcnt, rcnt)
+            d_q = torch.from_numpy(q).cuda()
+            d_out = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+            d_cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+            e.search_knn_dev(d_q.data_ptr(), nq, k, d_out.data_ptr(), d_cnt.data_ptr(), mode=mode)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_out.cpu().numpy().view(np.uint64), ref)
+        lin = e.search_knn(q[:6], k)[0]
+        for i in range(6):
+            assert np.array_equal(lin[i], oracle.linear_knn(codes, q[i], k))
+        with pytest.raises(ValueError):
+            e.search_knn(q, k, out=np.zeros((nq, k + 1), dtype=np.uint64))

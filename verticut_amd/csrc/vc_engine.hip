@@ -26,6 +26,7 @@ struct vc_engine {
   // grow-only work buffers
   void* d_stage = nullptr;      size_t stage_bytes = 0;   // ingest staging / query upload
   uint8_t* h_pin = nullptr;     size_t pin_bytes = 0;     // pinned host staging of the host-pointer search calls (queries | rows | counts)
+  uint8_t* h_pipe = nullptr;    hipEvent_t pipe_ev[2] = {nullptr, nullptr};   // two pinned chunks: large result sets on their way to pageable memory
   uint64_t* d_q = nullptr;      size_t q_bytes = 0;       // queries [nq][W]
   uint32_t* d_state = nullptr;  size_t state_bytes = 0;   // per tile: count | hist | shist | tau
   uint64_t* d_ring = nullptr;   size_t ring_bytes = 0;    // per tile: [qt][cap]
@@ -268,6 +269,9 @@ int vc_destroy(vc_engine* e) {
   (void)hipFree(e->d_cols);
   (void)hipFree(e->d_stage);
   if (e->h_pin) (void)hipHostFree(e->h_pin);
+  if (e->h_pipe) (void)hipHostFree(e->h_pipe);
+  for (hipEvent_t ev : e->pipe_ev)
+    if (ev) (void)hipEventDestroy(ev);
   (void)hipFree(e->d_q);
   (void)hipFree(e->d_state);
   (void)hipFree(e->d_ring);
@@ -917,6 +921,46 @@ int vc_search_knn_dev_stats(vc_engine* e, const void* d_queries, uint32_t nq, ui
   return rc;
 }
 
+// is `p` page-locked host memory (hipHostMalloc / hipHostRegister / torch pin_memory)?  Then a copy is one DMA, no staging.
+static bool host_pinned(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();   // ordinary malloc'ed memory is "invalid value" to the runtime
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+#define VC_PIPE_CHUNK ((size_t)1 << 20)
+// Large results to PAGEABLE host memory: the runtime's own staged copy is serial (DMA a chunk, memcpy it, next chunk); here the
+// DMA of chunk i+1 runs while the host copies chunk i out of the other pinned buffer.  Synchronises the stream.
+static int d2h_pipelined(vc_engine* e, void* dst, const void* d_src, size_t bytes) {
+  if (!e->h_pipe) {
+    if (hipHostMalloc((void**)&e->h_pipe, 2 * VC_PIPE_CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); e->h_pipe = nullptr; }
+    for (hipEvent_t& ev : e->pipe_ev)
+      if (e->h_pipe && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+  }
+  if (!e->h_pipe || !e->pipe_ev[0] || !e->pipe_ev[1]) {   // no pinned memory to be had: the runtime's staged copy
+    VC_HIP(e, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(e, hipStreamSynchronize(e->stream));
+    return VC_OK;
+  }
+  const size_t n_chunks = (bytes + VC_PIPE_CHUNK - 1) / VC_PIPE_CHUNK;
+  for (size_t c = 0; c <= n_chunks; ++c) {
+    if (c < n_chunks) {
+      const size_t off = c * VC_PIPE_CHUNK, len = std::min(VC_PIPE_CHUNK, bytes - off);
+      VC_HIP(e, hipMemcpyAsync(e->h_pipe + (c & 1) * VC_PIPE_CHUNK, (const uint8_t*)d_src + off, len, hipMemcpyDeviceToHost, e->stream));
+      VC_HIP(e, hipEventRecord(e->pipe_ev[c & 1], e->stream));
+    }
+    if (c > 0) {
+      const size_t off = (c - 1) * VC_PIPE_CHUNK, len = std::min(VC_PIPE_CHUNK, bytes - off);
+      VC_HIP(e, hipEventSynchronize(e->pipe_ev[(c - 1) & 1]));
+      memcpy((uint8_t*)dst + off, e->h_pipe + ((c - 1) & 1) * VC_PIPE_CHUNK, len);
+    }
+  }
+  return VC_OK;
+}
+
 int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, uint32_t mode, uint32_t order,
                   uint64_t* out, uint32_t* counts, vc_query_stats* stats) {
   int rc = check_knn_args(e, queries, nq, k, mode);
@@ -928,11 +972,15 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
   if ((rc = grow(e, &e->d_out, &e->out_bytes, (size_t)nq * k * 8))) return rc;
   if ((rc = grow(e, &e->d_cnt, &e->cnt_bytes, (size_t)nq * 8))) return rc;
   // Pageable host memory makes every async copy a staged, partly synchronous one (~20 us each at this size: a third of what the
-  // host-pointer call costs over the device-pointer call).  Batches of up to 4 MB go through a pinned staging buffer of the
+  // host-pointer call costs over the device-pointer call).  Batches of up to 512 KB go through a pinned staging buffer of the
   // engine: one memcpy in, one out, true async copies in between.
+  // Larger batches (an MIH call of 16 384 queries returns 13 MB of rows): straight DMA when the caller's buffers are page-locked,
+  // else the rows travel through two pinned chunks, DMA and host copy overlapped (d2h_pipelined).
   const size_t rows_bytes = (size_t)nq * k * 8, pin_need = ((qbytes + 63) & ~(size_t)63) + rows_bytes + (size_t)nq * 4;
   uint8_t *pin_q = nullptr, *pin_rows = nullptr, *pin_cnt = nullptr;
-  if (pin_need <= ((size_t)4 << 20)) {
+  const bool small = pin_need <= ((size_t)512 << 10);     // (one staging buffer, one host copy: 8 queries x top-100 and the like)
+  const bool out_direct = !small && host_pinned(out);
+  if (small) {
     if (pin_need > e->pin_bytes) {
       if (e->h_pin) (void)hipHostFree(e->h_pin);
       e->h_pin = nullptr;
@@ -955,16 +1003,20 @@ int vc_search_knn(vc_engine* e, const void* queries, uint32_t nq, uint32_t k, ui
   if (mode == VC_MODE_LINEAR) {
     rc = linear_batch(e, e->d_q, nq, k, e->d_out, e->d_cnt);
   } else {
-    st.resize(nq);
+    if (stats) st.resize(nq);      // (the statistics cost four read-backs and a wait per launch: only when asked for)
     const VcMihScanFallback fb{mih_scan_fallback, e, e->n_cu};
     rc = vc_mih_search(e->mih, e->d_cols, e->stride, e->n, e->d_q, nq, k, mode == VC_MODE_MIH_APPROX, e->d_out,
-                       e->d_cnt, st.data(), e->stream, &e->err, &fb);
+                       e->d_cnt, stats ? st.data() : nullptr, e->stream, &e->err, &fb);
   }
   timing_end(e);
   if (rc) return rc;
-  VC_HIP(e, hipMemcpyAsync(pin_rows ? (void*)pin_rows : (void*)out, e->d_out, rows_bytes, hipMemcpyDeviceToHost, e->stream));
   VC_HIP(e, hipMemcpyAsync(pin_cnt ? (void*)pin_cnt : (void*)cnt.data(), e->d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, e->stream));
-  VC_HIP(e, hipStreamSynchronize(e->stream));
+  if (small || out_direct) {
+    VC_HIP(e, hipMemcpyAsync(pin_rows ? (void*)pin_rows : (void*)out, e->d_out, rows_bytes, hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(e, hipStreamSynchronize(e->stream));
+  } else if ((rc = d2h_pipelined(e, out, e->d_out, rows_bytes))) {
+    return rc;
+  }
   if (pin_rows) {
     memcpy(out, pin_rows, rows_bytes);
     memcpy(cnt.data(), pin_cnt, (size_t)nq * 4);
