@@ -9,7 +9,7 @@ python -m pytest tests -m gpu -x -q --durations=5 > $O/pytest_gpu.txt 2>&1
 rc=$?
 tail -4 $O/pytest_gpu.txt
 [ $rc -ne 0 ] && exit $rc
-tools/profile_round4.sh r04c > $O/profile.log 2>&1 || { tail -5 $O/profile.log; exit 1; }
+tools/profile_round4.sh r04e > $O/profile.log 2>&1 || { tail -5 $O/profile.log; exit 1; }
 tail -3 $O/profile.log
 python tests/campaign/parity_campaign_mih.py $CASES $SEED > $O/campaign_mih.txt 2>&1 || { tail -5 $O/campaign_mih.txt; exit 1; }
 tail -1 $O/campaign_mih.txt
