@@ -847,7 +847,7 @@ struct QueryKernelParams {
   uint32_t* heavy_ctr;
   uint64_t* out;               // k-NN: [nq][k] rows
   uint32_t* out_cnt;
-  unsigned long long* phase_dbg;  // dev (VC_MIH_PHASES): [8] phase times of mih_query_kernel, summed over the launch; [8..13] block lifetimes by stop shell (0..4, handed over), [16..21] their counts, [24] start of the first block, [25..30] latest end by stop shell
+  unsigned long long* phase_dbg;  // dev (VC_MIH_PHASES): [8] phase times of mih_query_kernel, summed over the launch; [8..13] block lifetimes by stop shell (0..4, handed over), [16..21] their counts, [24] start of the first block, [25..30] latest end by stop shell, [32 + 8 c ..] the phase times of class c
   const uint32_t* order;       // k-NN: block b serves query order[b] (longest-first, mih_order_kernel); null = query b
   uint32_t use_lines;          // k-NN, 32-bit substrings: probe the directory lines (VcTableView::lines) instead of bitmap + blockoff + offsets
   uint32_t group;              // k-NN, 32-bit substrings: shells 0 .. group-1 share the first pass (1 = one shell per pass)
@@ -991,8 +991,8 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   __shared__ uint32_t s_bm[MQ_BMW + 1], s_bmpre[MQ_BMW + 1];
 
   __shared__ unsigned long long s_t_entry;   // dev (VC_MIH_PHASES): thread 0's clock at entry -- in LDS, not in a register pair that lives to the end
-  __shared__ unsigned long long s_ph_last;
-  __shared__ uint32_t s_ph_cur;
+  __shared__ unsigned long long s_ph_last, s_phacc[8];   // (phase times of THIS block: flushed once, by stop shell, when it ends --
+  __shared__ uint32_t s_ph_cur;                            //  an atomic per phase change on launch-wide words made the instrumented kernel 2.4 x slower)
   __shared__ unsigned long long s_stat[5];
   const uint32_t slot = p.order ? p.order[blockIdx.x] : blockIdx.x;   // (block-uniform: a scalar load)
   const uint32_t tid = threadIdx.x, lane = vc_lane(), wave = tid / VC_WAVE;
@@ -1079,16 +1079,23 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   auto tick = [&](uint32_t next) {   // ends the current phase, starts `next`
     if (p.phase_dbg && tid == 0) {
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      atomicAdd(&p.phase_dbg[s_ph_cur], now - s_ph_last);
+      s_phacc[s_ph_cur] += now - s_ph_last;
       s_ph_last = now;
       s_ph_cur = next;
     }
   };
   if (p.phase_dbg && tid == 0) {
+    for (int i = 0; i < 8; ++i) s_phacc[i] = 0;
     s_ph_last = __builtin_amdgcn_s_memrealtime();
     s_ph_cur = 0;
-    atomicAdd(&p.phase_dbg[7], s_ph_last - s_t_entry);   // set-up: query, tables, binomials, masks
+    s_phacc[7] = s_ph_last - s_t_entry;   // set-up: query, tables, binomials, masks
   }
+  auto phase_flush = [&](uint32_t cls) {   // thread 0, at the block's end: cls = stop shell 0..4, 5 = handed over
+    for (int i = 0; i < 8; ++i) {
+      atomicAdd(&p.phase_dbg[i], s_phacc[i]);
+      atomicAdd(&p.phase_dbg[32 + cls * 8 + i], s_phacc[i]);
+    }
+  };
   uint32_t r_base = 0;             // first shell of the current pass: a candidate's class = its substring distance - r_base (block-uniform)
   uint32_t kk = 0;                 // radius mode: sorted results in s_buf[0..kk)           (block-uniform)
   bool spilled = false;            // radius mode: results went to the global ring unsorted (block-uniform)
@@ -1746,6 +1753,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
           atomicAdd(&p.phase_dbg[16 + min(rr, 4u)], 1ull);
           atomicMin(&p.phase_dbg[24], s_t_entry);
           atomicMax(&p.phase_dbg[25 + min(rr, 4u)], now);
+          phase_flush(min(rr, 4u));
         }
         return;
       }
@@ -1787,6 +1795,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
       atomicAdd(&p.phase_dbg[21], 1ull);
       atomicMin(&p.phase_dbg[24], s_t_entry);
       atomicMax(&p.phase_dbg[30], now);
+      phase_flush(5);
     }
   }
 }
@@ -3099,9 +3108,9 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
   QueryKernelParams p = p_in;
   static unsigned long long* d_phase = nullptr;   // dev knob VC_MIH_PHASES: one buffer per process is enough
   if (ix->knobs.mih_phases && p.mode != MQ_MODE_RADIUS) {
-    if (!d_phase && hipMalloc((void**)&d_phase, 256) != hipSuccess) d_phase = nullptr;
+    if (!d_phase && hipMalloc((void**)&d_phase, 1024) != hipSuccess) d_phase = nullptr;
     if (d_phase) {
-      (void)hipMemsetAsync(d_phase, 0, 256, s);
+      (void)hipMemsetAsync(d_phase, 0, 1024, s);
       (void)hipMemsetAsync(d_phase + 24, 0xFF, 8, s);
     }
     p.phase_dbg = d_phase;
@@ -3135,12 +3144,20 @@ static hipError_t timed_query_launch(VcMihIndex* ix, const QueryKernelParams& p_
                      p.heavy_ctr ? p.heavy_ctr - 2 : (uint32_t*)nullptr,
                      p.heavy_ctr ? (volatile uint32_t*)ix->h_ctr_dev : (volatile uint32_t*)nullptr, ++ix->ctr_seq);
   if (p.phase_dbg) {
-    unsigned long long h[32];
-    if (hipMemcpyAsync(h, p.phase_dbg, 256, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+    unsigned long long h[128];
+    if (hipMemcpyAsync(h, p.phase_dbg, 1024, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
       fprintf(stderr, "[vc_mih lifetimes] stop shell: blocks, mean lifetime us, last end (us after the first block's start):");
       for (int c = 0; c < 6; ++c)
         if (h[16 + c]) fprintf(stderr, "  %s%d: %llu, %.1f, %.1f", c == 5 ? "handed over after " : "", c == 5 ? (int)p.r_last : c, h[16 + c], h[8 + c] * 0.01 / h[16 + c], (h[25 + c] - h[24]) * 0.01);
       fprintf(stderr, "\n");
+      for (int c = 0; c < 6; ++c)
+        if (h[16 + c]) {
+          const unsigned long long* q = h + 32 + c * 8;
+          const double nb = (double)h[16 + c];
+          fprintf(stderr, "[vc_mih phases] %s%d (%llu blocks), us per block: set-up %.1f | plan+scan %.1f | directory %.1f | verify %.1f | evaluate %.1f | finish %.1f | out %.1f\n",
+                  c == 5 ? "handed over after " : "stop shell ", c == 5 ? (int)p.r_last : c, h[16 + c], (q[7] + q[0]) * 0.01 / nb, q[1] * 0.01 / nb,
+                  q[2] * 0.01 / nb, q[3] * 0.01 / nb, q[4] * 0.01 / nb, q[5] * 0.01 / nb, q[6] * 0.01 / nb);
+        }
     }
     fprintf(stderr, "[vc_mih phases] %u blocks, us per block: set-up %.1f | plan+scan %.1f | directory %.1f | verify %.1f | evaluate %.1f | finish %.1f | out %.1f\n", nq,
               (h[7] + h[0]) * 0.01 / nq, h[1] * 0.01 / nq, h[2] * 0.01 / nq, h[3] * 0.01 / nq, h[4] * 0.01 / nq, h[5] * 0.01 / nq, h[6] * 0.01 / nq);
