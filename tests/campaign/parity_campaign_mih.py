@@ -119,6 +119,24 @@ def main():
                     print("MISMATCH case %d query %d: %s" % (i, r, desc), flush=True)
                     return 1
                 checked += 1
+            # every seventh case: the same queries repeated into ONE call of 4 100 .. 9 000 (a launch of up to 16 384 slots, the
+            # per-slot state laid out for it; the regular cases stay below the 4 096-slot minimum) -- every copy's row, count
+            # and statistics must equal the small call's, which the oracle has just checked
+            if i % 7 == 5:
+                reps = int(rng.integers(4100, 9000)) // nq + 1
+                gb, cb, sb = e.search_knn(np.tile(q, (reps, 1)), k, mode=mode, with_stats=True)
+                same = np.array_equal(gb.reshape(reps, nq, k), np.broadcast_to(got, (reps, nq, k))) and \
+                    np.array_equal(cb.reshape(reps, nq), np.broadcast_to(cnt, (reps, nq)))
+                for j in (0, reps // 2, reps - 1):
+                    for r in range(nq):
+                        a_, b_ = sb[j * nq + r], st[r]
+                        same = same and (a_.radius, a_.n_sub_reads, a_.n_local_reads, a_.n_candidates, a_.n_results) == \
+                            (b_.radius, b_.n_sub_reads, b_.n_local_reads, b_.n_candidates, b_.n_results)
+                if not same:
+                    print("BIG-CALL MISMATCH case %d (%d x %d queries): %s" % (i, reps, nq, desc), flush=True)
+                    return 1
+                checked += reps * nq
+                desc += " [call of %d]" % (reps * nq)
             # radius search through both paths against numpy
             rad = int(rng.integers(0, 2 * m + 2))
             a = e.search_radius(q[:4], rad, mode=vc.MODE_MIH_EXACT) if not signext else None
