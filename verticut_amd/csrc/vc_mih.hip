@@ -981,7 +981,7 @@ __global__ void __launch_bounds__(MQ_BLK, (W <= 2 ? MQ_MINW : 0)) mih_query_kern
   uint32_t* s_binom = s_meta + MQ_HMAX;                      // [33][MQ_BW]
   uint32_t* s_mask = s_binom + 33 * MQ_BW;                   // [m][MQ_NJ][MQ_GW] (32-bit substrings only)
   const uint32_t HB = mq_hist_bins(W);
-  uint32_t* s_hist = s_mask + (p.sbits == 32 ? p.m * (MQ_LO_MAX + 1) * ((1u << MQ_LO_MAX) / 32u) : 0u);   // [MQ_MAX_GROUP][HB] (k-NN modes)
+  uint32_t* s_hist = s_mask + (p.sbits == 32 ? p.m * MQ_NJ * MQ_GW : 0u);   // [MQ_MAX_GROUP][HB] (k-NN modes)
   VcTableView* s_tv = (VcTableView*)(((uintptr_t)(s_hist + MQ_MAX_GROUP * HB) + 15) & ~(uintptr_t)15);      // [m]
   // s_seenc / s_hits0c [class]: distinct items verified / table 0's set leaves, per shell class of the current pass
   __shared__ uint32_t s_nh, s_ncand, s_seenc[MQ_MAX_GROUP], s_hits0c[MQ_MAX_GROUP], s_dk, s_wsum[MQ_BLK / VC_WAVE < 4 ? 4 : MQ_BLK / VC_WAVE];   // (s_wsum doubles as the 4 class counters of mq_select_exact)
@@ -2441,7 +2441,7 @@ struct VcMihIndex {
     }                                                                                                    \
   } while (0)
 
-static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits, uint32_t W);
+static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits, uint32_t W, uint32_t lo);
 static uint32_t grid_for(uint64_t n, uint32_t n_cu) { return (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)n_cu * 16); }
 
 static size_t device_lds_per_block() {
@@ -3075,15 +3075,15 @@ static hipError_t launch_probe(const ProbeParams& p, uint32_t W, uint32_t n_list
   return hipGetLastError();
 }
 
-static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits, uint32_t W = VC_MAX_W) {
+static size_t query_kernel_lds(uint32_t buf_entries, uint32_t m, uint32_t sbits, uint32_t W = VC_MAX_W, uint32_t lo = MQ_LO_MAX) {
   return (size_t)buf_entries * 8 + (size_t)(3 * MQ_HMAX + 1) * 4 + (size_t)33 * MQ_BW * 4 +
-         (sbits == 32 ? (size_t)m * (MQ_LO_MAX + 1) * ((1u << MQ_LO_MAX) / 32u) * 4 : 0) +   // masks sized for the widest granule
+         (sbits == 32 ? (size_t)m * (lo + 1) * ((1u << lo) / 32u) * 4 : 0) +                    // masks: [m][lo + 1] granules of 2^lo bits
          (size_t)MQ_MAX_GROUP * mq_hist_bins(W) * 4 + 16 +                                      // k-NN distance histograms, one per shell class
          (size_t)m * sizeof(VcTableView) + 16;                                                   // the tables' views
 }
 
 static hipError_t launch_query_kernel(const QueryKernelParams& p, uint32_t W, uint32_t nq, hipStream_t s) {
-  const size_t lds = query_kernel_lds(p.buf_entries, p.m, p.sbits, W);
+  const size_t lds = query_kernel_lds(p.buf_entries, p.m, p.sbits, W, p.mode == MQ_MODE_RADIUS ? MQ_LO_RADIUS : MQ_LO_KNN);
 #define MQ_LAUNCH_K(K_) hipLaunchKernelGGL((K_), dim3(nq), dim3(MQ_BLK), lds, s, p)
 #define MQ_LAUNCH(W_)                                                                                           \
   case W_:                                                                                                      \
@@ -3362,7 +3362,7 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
   // the query kernel's LDS request (top-k + candidate buffer, hit lists, binomials, masks) must fit a workgroup of this
   // device (k = 3073..7168 asks for ~82 KB); otherwise every shell runs through the multi-block kernels
   const bool inblock = ix->knobs.mih_host_loop == 0 && buf_entries <= 8192 && ix->m <= 64 &&
-                       query_kernel_lds(buf_entries, ix->m, S, ix->W) <= ix->lds_per_block;
+                       query_kernel_lds(buf_entries, ix->m, S, ix->W, MQ_LO_KNN) <= ix->lds_per_block;
   // the call's queries in as few launches as the tile limit allows, equally filled (20 000 queries = 2 x 10 000, not 16 384 + 3 616)
   const uint32_t QM = qtile_max(ix);
   const uint32_t n_tiles = std::max(1u, (nq + QM - 1) / QM);
