@@ -1003,7 +1003,7 @@ def run_c1(args, env, emit):
     from verticut_amd import engine as vc
     n, bits, Q, k = int(args.n), args.bits, args.queries, args.k
     rng = np.random.default_rng(args.seed + 1)
-    e = vc.Engine(bits, capacity=n, flags=vc.FLAG_LEAN_TIMING)      # default query tile (32): 200 queries = 7 passes over 8 MB
+    e = vc.Engine(bits, capacity=n, flags=vc.FLAG_LEAN_TIMING)      # query tile left to the engine: 8 MB of codes -> the 200 queries of a call in ONE pass
     e.add_synthetic(n, seed=args.seed)
     host_q = [rng.integers(0, 256, size=(Q, bits // 8), dtype=np.uint8) for _ in range(2)]
     dev_q = [torch.from_numpy(h).to(env.device) for h in host_q]
@@ -1051,7 +1051,7 @@ def run_c1(args, env, emit):
         "config": {
             "workload": "BASELINE configs[0]: linear_search.cc brute-force k-NN, %d-bit codes, %d synthetic images (2^20), %d queries per "
                         "run (the reference's cap), top-%d; the reference runs this shape on the CPU only -- its rows are cpu_baseline" % (bits, n, Q, k),
-            "n_codes": n, "bits": bits, "k": k, "queries_per_step": Q, "query_tile": 32, "query_kind": "uniform random", "seed": args.seed,
+            "n_codes": n, "bits": bits, "k": k, "queries_per_step": Q, "query_tile": "left to the engine (vc_config.query_tile = 0): 8 MB of codes -> up to 512 queries per pass, i.e. the 200 queries of a call in one pass", "query_kind": "uniform random", "seed": args.seed,
             "api": "vc_search_knn_dev: queries and results resident in HBM",
             "host_pointer_api": {"value": Q * host_steps / host_elapsed, "unit": "queries/s", "ms_per_step": host_elapsed / host_steps * 1e3,
                                  "what": "the same step through vc_search_knn (H2D of the queries, D2H of the rows, synchronous)"},

@@ -87,7 +87,9 @@ typedef struct vc_config {
   int32_t device;        /* HIP device ordinal, -1 = current */
   uint32_t cand_cap;     /* per-query candidate ring entries, 0 = default (65536) */
   uint32_t scan_blocks;  /* 0 = default grid for the verify kernel (tuning knob) */
-  uint32_t query_tile;   /* queries verified per DB pass; 0 = default (32).  8 = HBM-bound pass, see DESIGN.md 4.1 */
+  uint32_t query_tile;   /* queries verified per DB pass; 0 = the engine chooses: 32 for databases of 256 MB and more, doubling
+                            per halving below (at most 512: a small database's pass is priced by its launches, not its bytes).
+                            8 = HBM-bound pass, see DESIGN.md 4.1 */
   uint32_t timing_sample;/* with VC_FLAG_LEAN_TIMING: time only every N-th verify launch (0/1 = every launch) */
   uint32_t reserved[4];
 } vc_config;

@@ -19,6 +19,7 @@ struct vc_engine {
   int device = 0;
   uint32_t bits = 0, W = 0, m = 0, sbits = 0, n_cu = 0;
   uint32_t cap = 65536, qtile = 32, scan_blocks = 0;
+  bool qtile_auto = true;        // vc_config.query_tile == 0 and no VC_QUERY_TILE: the tile follows the database size (linear_tile)
   uint64_t n = 0, stride = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   uint64_t* d_cols = nullptr;
@@ -195,7 +196,8 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
   // queries verified per database pass: 8 keeps the pass on the HBM side of the roofline (bench), larger tiles trade
   // bandwidth efficiency for queries/s until the popcount VALU ceiling; default for big batches: 32
   e->qtile = cfg->query_tile ? cfg->query_tile : 32u;
-  if (const char* s = getenv("VC_QUERY_TILE")) e->qtile = (uint32_t)std::max(1, atoi(s));
+  e->qtile_auto = cfg->query_tile == 0;
+  if (const char* s = getenv("VC_QUERY_TILE")) { e->qtile = (uint32_t)std::max(1, atoi(s)); e->qtile_auto = false; }
   e->scan_blocks = cfg->scan_blocks;
   if (const char* s = getenv("VC_SCAN_BLOCKS")) e->scan_blocks = (uint32_t)std::max(1, atoi(s));
   e->stride = (cfg->capacity + VC_PAD_ITEMS - 1) / VC_PAD_ITEMS * VC_PAD_ITEMS;
@@ -555,9 +557,22 @@ struct LinearBufs {
 #define VC_GROUP_QUERIES 64u
 #define VC_RESIDENT_MB_DEFAULT 240   // of the 256 MB Infinity Cache (profiles/r02_sweeps.md: 224-256 MB best, 320 MB thrashes)
 
+// Queries per database pass when the caller left it to the engine (vc_config.query_tile = 0).  A pass over a BIG database is
+// priced by its bytes and 32 queries keep it near the VALU / HBM balance point; a pass over a small one is priced by its
+// launches (~50 us of bootstrap / verify / select / recover whatever it reads), so the tile grows as the database shrinks:
+// 32 from 256 MB on, doubling per halving below, at most 512 -- configs[0] (8 MB, 200 queries per call) runs in ONE pass
+// instead of seven: 0.42 -> 0.92 M queries/s.
+static uint32_t linear_tile(const vc_engine* e) {
+  if (!e->qtile_auto) return e->qtile;
+  const uint64_t bytes = std::max<uint64_t>(e->n, 1) * (e->bits / 8);
+  uint32_t t = 32;
+  for (uint64_t b = bytes; b < ((uint64_t)256 << 20) && t < 512; b <<= 1) t <<= 1;
+  return t;
+}
+
 static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
   b->hs = (e->bits + 1 + 7) & ~7u;
-  b->QT = std::min(e->qtile, nq);
+  b->QT = std::min(linear_tile(e), nq);
   b->GQ = std::min(nq, std::max(b->QT, VC_GROUP_QUERIES / b->QT * b->QT));   // whole tiles, >= one tile
   b->cap = std::max(e->cap, 4 * k);
   // count[GQ] and tau[GQ] hold one 128-byte line per query (VC_QUERY_LINE_WORDS); the histograms are dense
@@ -858,9 +873,12 @@ static int mih_scan_fallback(void* ctx, const uint64_t* d_q, const uint32_t* d_l
     return VC_OK;
   };
   const uint32_t saved_tile = e->qtile;
+  const bool saved_auto = e->qtile_auto;
   e->qtile = 8;                                   // HBM-bound passes
+  e->qtile_auto = false;
   rc = linear_batch(e, e->d_fq, n, k, e->d_frows, e->d_fcnt, &hook);
   e->qtile = saved_tile;
+  e->qtile_auto = saved_auto;
   if (rc) return rc;
   if (want_stats)
     VC_HIP(e, vc_launch_minsub_count(e->d_cols, e->stride, e->n, e->W, e->m, e->sbits, e->d_fq, d_list, d_flag, n, tgt.radius, tgt.seen, e->n_cu, s));
