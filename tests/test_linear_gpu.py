@@ -260,3 +260,24 @@ def test_timing_reports_scan(vc):
         e.search_knn(q, 10)
         t = e.timing()
         assert t.scan_launches == 1 and t.calls == 1 and t.scan_bytes == (1 << 20) * 16 and t.scan_ms > 0
+
+
+@pytest.mark.parametrize("bits,n,nq", [(64, 200_000, 150), (128, 50_000, 300), (256, 20_000, 40)])
+def test_tile_and_tile_shape_follow_a_small_database(vc, oracle, bits, n, nq):
+    """An engine whose query tile is left to it (vc_config.query_tile = 0) sizes the tile by the database -- a pass over a few MB
+    is priced by its launches, so all of a call's queries (up to 512) share one pass -- and fits the verify kernel's lane tile to
+    the few chunks there are (linear_tile, vc_scan_pick_shape).  Same rows as the fixed tile of 32 (five / ten / two passes
+    here), as a tile of 8 (the headline's kernel form) and as the oracle's linear_search.cc:39-64 restatement."""
+    rng = np.random.default_rng(bits + nq)
+    codes = oracle.gen_codes(n, bits, 9, kind=1, n_centres=100, max_flips=9)
+    q = _queries(oracle, codes, nq, rng)
+    k = 64
+    rows = {}
+    for tile in (0, 32, 8):
+        with vc.Engine(bits, capacity=n, query_tile=tile) as e:
+            e.add_codes(codes)
+            rows[tile] = e.search_knn(q, k)
+    for tile in (32, 8):
+        assert np.array_equal(rows[0][0], rows[tile][0]) and np.array_equal(rows[0][1], rows[tile][1])
+    exp, ecnt = _expect(oracle, codes, q[:24], k)
+    assert np.array_equal(rows[0][0][:24], exp) and np.array_equal(rows[0][1][:24], ecnt)

@@ -561,7 +561,7 @@ struct LinearBufs {
 // priced by its bytes and 32 queries keep it near the VALU / HBM balance point; a pass over a small one is priced by its
 // launches (~50 us of bootstrap / verify / select / recover whatever it reads), so the tile grows as the database shrinks:
 // 32 from 256 MB on, doubling per halving below, at most 512 -- configs[0] (8 MB, 200 queries per call) runs in ONE pass
-// instead of seven: 0.42 -> 0.92 M queries/s.
+// instead of seven: 0.42 -> 0.92 M queries/s (1.3 M with the lane tile of vc_scan_pick_shape fitted to it as well).
 static uint32_t linear_tile(const vc_engine* e) {
   if (!e->qtile_auto) return e->qtile;
   const uint64_t bytes = std::max<uint64_t>(e->n, 1) * (e->bits / 8);
@@ -597,7 +597,10 @@ static int linear_bufs(vc_engine* e, uint32_t nq, uint32_t k, LinearBufs* b) {
 // one verify launch for a tile whose tau is already set (the tile's state starts at query t0 of the group); d_limit may be null
 static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint32_t qt, uint32_t k, const uint64_t* d_limit,
                      uint32_t t0 = 0, const uint32_t* d_shist = nullptr, uint64_t shist_cstride = 0) {
-  const VcScanShape sh = vc_scan_pick_shape(e->W, qt, nullptr, &e->knobs);
+  // (the shape follows a small database only where the TILE does too -- query_tile left to the engine -- and only for tiles
+  // beyond the small-tile form: explicit tiles and <= 8 queries keep the headline's kernel, on any database)
+  const uint64_t shape_n = (e->qtile_auto && qt > 8) ? e->n : 0;
+  const VcScanShape sh = vc_scan_pick_shape(e->W, qt, nullptr, &e->knobs, shape_n);
   VcScanParams p{};
   p.cols = e->d_cols;
   p.stride = e->stride;
@@ -638,7 +641,7 @@ static int scan_tile(vc_engine* e, const LinearBufs& b, const uint64_t* dq, uint
     VC_HIP(e, hipMemsetAsync(d_trace, 0, trace_blocks * 16 + 256, e->stream));
     p.trace = d_trace;
   }
-  VC_HIP(e, vc_launch_scan(p, e->W, e->n_cu, e->scan_blocks, &e->knobs, e->stream));
+  VC_HIP(e, vc_launch_scan(p, e->W, e->n_cu, e->scan_blocks, &e->knobs, e->stream, shape_n));
   if (d_trace) {
     std::vector<uint64_t> h(trace_blocks * 2 + 32);
     VC_HIP(e, hipMemcpyAsync(h.data(), d_trace, trace_blocks * 16 + 256, hipMemcpyDeviceToHost, e->stream));

@@ -47,7 +47,7 @@ struct VcScanShape {
   int small;    // tiles of <= 8 queries use the compile-time-unrolled form of the kernel
   uint64_t chunk_items() const { return 2ull * blk * unroll; }
 };
-VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes, const VcKnobs* knobs);
+VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes, const VcKnobs* knobs, uint64_t n_items = 0);
 
 float vc_probe_stream_ms(const uint64_t* cols, uint64_t stride, uint32_t W, uint64_t items, uint64_t* d_sink, uint32_t n_cu,
                          hipStream_t s);
@@ -64,10 +64,12 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
                                  const uint64_t* d_queries, uint32_t qt, uint32_t* d_shist, uint32_t hist_stride,
                                  uint32_t k, uint32_t bits, uint32_t* d_tau, uint32_t qs, bool refine, uint32_t n_cu,
                                  uint32_t blocks_per_cu, hipStream_t s, bool cut = true);
-bool vc_scan_is_small(uint32_t W, uint32_t qt, const VcKnobs* knobs);
+bool vc_scan_is_small(uint32_t W, uint32_t qt, const VcKnobs* knobs, uint64_t n_items = 0);
 // grid = min(chunks, CUs x resident blocks per CU, want_blocks if non-zero)
+// shape_n: 0, or the database size when the caller wants the tile shape fitted to a small database (vc_scan_pick_shape; the
+// caller's nchunks must come from the same shape)
 hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, const VcKnobs* knobs,
-                          hipStream_t s);
+                          hipStream_t s, uint64_t shape_n = 0);
 // ring -> sorted top-k (per query); out padded with VC_PACK_INF
 // d_tau (nullable): final per-query distance thresholds of the scan -- farther entries are dropped before sorting
 hipError_t vc_launch_select_ring(const uint64_t* d_buf, uint32_t cap, const uint32_t* d_count, const uint32_t* d_tau, uint32_t qs,

@@ -1269,7 +1269,7 @@ hipError_t launch_scan_w(const VcScanParams& p, const VcScanShape& sh, size_t ld
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
-VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes, const VcKnobs* knobs) {
+VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes, const VcKnobs* knobs, uint64_t n_items) {
   const size_t lds = (size_t)qt * (W * 8 + 4);
   if (lds_bytes) *lds_bytes = lds;
   VcScanShape sh;
@@ -1279,6 +1279,10 @@ VcScanShape vc_scan_pick_shape(uint32_t W, uint32_t qt, size_t* lds_bytes, const
   sh.blk = lds > 40 * 1024 ? 512 : 256;
   sh.dbuf = 2;
   sh.small = knobs ? knobs->scan_small : 1;
+  // A small database (n_items given): fewer items per lane, so that its chunks reach every wave of the grid -- 2^20 codes in
+  // chunks of 2048 items are 512 blocks' worth, two waves per SIMD walking 200 queries each with nothing to hide their chains
+  // behind (configs[0]: 0.143 -> 0.077 ms per pass with one item pair per lane)
+  while (n_items && sh.unroll > 1 && n_items < sh.chunk_items() * 2048) sh.unroll >>= 1;
   if (knobs && knobs->shape_set) {  // dev knob VC_SCAN_SHAPE "U,BLK,DB" (read at vc_create)
     const int u = knobs->shape_u ? knobs->shape_u : sh.unroll, b = knobs->shape_blk ? knobs->shape_blk : sh.blk, d = knobs->shape_db;
     if ((u == 1 || u == 2 || u == 4) && u * (int)W <= 8) sh.unroll = u;
@@ -1376,17 +1380,17 @@ hipError_t vc_launch_sample_hist(const uint64_t* cols, uint64_t stride, uint32_t
 }
 
 // true when a tile of qt queries runs the small-tile form of the verify kernel (which can cut the bootstrap histograms itself)
-bool vc_scan_is_small(uint32_t W, uint32_t qt, const VcKnobs* knobs) {
-  const VcScanShape sh = vc_scan_pick_shape(W, qt, nullptr, knobs);
+bool vc_scan_is_small(uint32_t W, uint32_t qt, const VcKnobs* knobs, uint64_t n_items) {
+  const VcScanShape sh = vc_scan_pick_shape(W, qt, nullptr, knobs, n_items);
   const int ud = W <= 2 ? 4 : (W <= 4 ? 2 : 1);
   return sh.small && sh.blk == 256 && sh.dbuf == 2 && qt <= 8 && sh.unroll == ud && !VC_SCAN_DIAGNOSTICS;
 }
 
 hipError_t vc_launch_scan(const VcScanParams& p, uint32_t W, uint32_t n_cu, uint32_t want_blocks, const VcKnobs* knobs,
-                          hipStream_t s) {
+                          hipStream_t s, uint64_t shape_n) {
   if (p.nchunks == 0 || p.qt == 0) return hipSuccess;
   size_t lds;
-  const VcScanShape sh = vc_scan_pick_shape(W, p.qt, &lds, knobs);
+  const VcScanShape sh = vc_scan_pick_shape(W, p.qt, &lds, knobs, shape_n);
   switch (W) {
     case 1: return launch_scan_w<1>(p, sh, lds, n_cu, want_blocks, s);
     case 2: return launch_scan_w<2>(p, sh, lds, n_cu, want_blocks, s);
