@@ -877,7 +877,9 @@ static int mih_scan_fallback(void* ctx, const uint64_t* d_q, const uint32_t* d_l
   };
   const uint32_t saved_tile = e->qtile;
   const bool saved_auto = e->qtile_auto;
-  e->qtile = 8;                                   // HBM-bound passes
+  // 32 queries per pass: a pass of 8 sits on the HBM roofline, but the switch is asked for QUERIES, and per query the VALU-bound
+  // pass of 32 is the cheaper one (8.2 ms per 32 against 2.5 ms per 8 at 1e9 x 128 bit: 3 900 against 3 200 queries/s)
+  e->qtile = 32;
   e->qtile_auto = false;
   rc = linear_batch(e, e->d_fq, n, k, e->d_frows, e->d_fcnt, &hook);
   e->qtile = saved_tile;

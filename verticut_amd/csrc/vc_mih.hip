@@ -3333,6 +3333,14 @@ __global__ void mih_stats_export_kernel(MihState st, const uint32_t* __restrict_
   out[i] = o;
 }
 
+// What the verify kernel charges for nq queries (the cost-model switch, vc_engine.hip mih_scan_fallback: passes of up to 32
+// queries): a pass streams the shard at ~6 TB/s or, from ~10 queries on, runs at the xor / popcount issue rate -- 8.2 ms per 32
+// queries over 1e9 x 128 bit, i.e. 1.3e-13 s per (query x 64-bit word) -- plus ~40 us of launches.
+static double scan_cost_s(uint64_t n, uint32_t W, uint32_t nq) {
+  auto pass = [&](uint32_t qt) { return std::max((double)n * W * 8 / 6e12, (double)qt * n * W * 1.3e-13) + 40e-6; };
+  return (double)(nq / 32) * pass(32) + (nq % 32 ? pass(nq % 32) : 0.0);
+}
+
 int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint64_t n, const uint64_t* d_q, uint32_t nq,
                   uint32_t k, bool approximate, uint64_t* d_out, uint32_t* d_cnt, vc_query_stats* host_stats, hipStream_t s,
                   std::string* err, const VcMihScanFallback* fb, vc_query_stats* d_stats) {
@@ -3439,11 +3447,10 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
         MIH_CHECK(hipGetLastError());
         if (fb && fb->fn && switch_ok) {
           // Cost model, per query: the hand-over left an upper bound of the probes each query may still need (its k-th
-          // distance so far bounds its last shell).  The multi-block kernels sustain ~4e10 probes/s; a verify pass streams the
-          // shard once per 8 queries at ~6 TB/s (x 2.5 with the statistics pass).  Queries beyond the break-even are answered
+          // distance so far bounds its last shell).  The multi-block kernels sustain ~4e10 probes/s; the verify kernel's price per
+          // query is scan_cost_s's (x 2.5 with the statistics pass).  Queries beyond the break-even are answered
           // by the scan NOW, stop rule replayed (mih_replay_kernel) -- the others keep their radius loop.
-          const double pass_s = (double)n * ix->W * 8 / 6e12 + 40e-6;
-          const double limit = ix->knobs.mih_switch == 2 ? -1.0 : pass_s / 8 * (stats ? 2.5 : 1.0) * 4e10;
+          const double limit = ix->knobs.mih_switch == 2 ? -1.0 : scan_cost_s(n, ix->W, 32) / 32 * (stats ? 2.5 : 1.0) * 4e10;
           MIH_CHECK(hipMemsetAsync(d_ctr, 0, 8, s));
           hipLaunchKernelGGL(mih_partition_kernel, dim3((n_heavy + 255) / 256), dim3(256), 0, s, (const uint32_t*)cur, n_heavy, st.work,
                              limit < 0 ? 0ull : (unsigned long long)limit, nxt, redo, d_ctr);
@@ -3475,12 +3482,12 @@ int vc_mih_search(VcMihIndex* ix, const uint64_t* d_cols, uint64_t stride, uint6
     bool switched = false;
     for (uint32_t r = r_start; r <= S && n_cur; ++r) {       // search_worker.cc:170: radius <= n_local_bytes_*8
       // Cost model: this shell alone is m * C(S, r) bucket probes per active query (the multi-block kernels sustain ~4e10
-      // probes/s plus ~40 us of launches and a host round trip per shell); a verify pass streams the shard once per 8
-      // queries at ~6 TB/s (x 2.5 when the statistics pass is wanted).  Beyond the break-even the remaining queries are
+      // probes/s plus ~40 us of launches and a host round trip per shell); the verify kernel costs scan_cost_s (x 2.5 when the
+      // statistics pass is wanted).  Beyond the break-even the remaining queries are
       // answered by the scan with the stop rule replayed -- same rows, same statistics (see mih_replay_kernel).
       if (fb && fb->fn && switch_ok && !switched) {
         const double est_mih = (double)n_cur * ix->m * binom_host(S, r) / 4e10 + 40e-6;
-        const double est_scan = (double)((n_cur + 7) / 8) * ((double)n * ix->W * 8 / 6e12 + 40e-6) * (stats ? 2.5 : 1.0);
+        const double est_scan = scan_cost_s(n, ix->W, n_cur) * (stats ? 2.5 : 1.0);
         if (est_mih > est_scan || ix->knobs.mih_switch == 2) {
           VcMihScanTarget tgt{st.ring, cap, st.count, st.radius, st.seen, st.sub, st.loc};
           MIH_CHECK(hipMemsetAsync(d_ctr, 0, 8, s));
