@@ -776,6 +776,8 @@ def _extras_knn_mih(args, env, n, tag, legs, steps=6):
                     r["verify_kernel"] = _scan_fields(tm)
                     r["verify_kernel"]["kernel_ms_per_step"] = tm.scan_ms / nst
                     if leg == "uniform":
+                        r["verify_kernel"]["note"] = ("the switch runs verify passes of up to 32 queries: per query the VALU-bound pass of 32 is cheaper than the "
+                                                      "HBM-bound pass of 8 (extras.qt32 vs the headline), so `frac` -- the pass's share of the HBM peak -- is ~0.25 by design")
                         r["mih_kernel_frac"] = r["frac"]
                         r["frac"] = r["verify_kernel"]["frac"]
                         r["kernel"] = "vc_scan_kernel (dominant: %.3f of %.3f ms per step) behind mih_query_kernel" % (tm.scan_ms / nst, elapsed / nst * 1e3)
